@@ -1,0 +1,36 @@
+# Top-level build: host model layer, HIP engine, command line driver; `make oracle` builds the test oracle.
+# No cmake: plain g++ / hipcc (gfx950 only).
+CXX      ?= g++
+HIPCC    ?= /opt/rocm/bin/hipcc
+# host code generation matches the reference's Release build (-O3, no -march => no FMA contraction) so that
+# setup-time tables are bit-identical to SKIRT's
+CXXFLAGS := -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter
+HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wall -Wno-unused-parameter
+
+HOST_SRC := $(wildcard skirt9_amd/host/*.cpp)
+HOST_HDR := $(wildcard skirt9_amd/host/*.hpp) $(wildcard include/*.h)
+HOST_LIB_SRC := $(filter-out skirt9_amd/host/main.cpp,$(HOST_SRC))
+
+all: skirt9_amd/lib/libskirthost.so skirt9_amd/lib/libpmc.so skirt9_amd/lib/skirt_mi355x
+
+skirt9_amd/lib/libskirthost.so: $(HOST_LIB_SRC) $(HOST_HDR)
+	@mkdir -p skirt9_amd/lib
+	$(CXX) $(CXXFLAGS) -shared $(HOST_LIB_SRC) -o $@
+
+skirt9_amd/lib/libpmc.so: $(wildcard skirt9_amd/csrc/*.hip) $(wildcard skirt9_amd/csrc/*.h) $(wildcard include/*.h)
+	@mkdir -p skirt9_amd/lib
+	$(HIPCC) $(HIPFLAGS) -shared $(wildcard skirt9_amd/csrc/*.hip) -o $@
+
+skirt9_amd/lib/skirt_mi355x: skirt9_amd/host/main.cpp skirt9_amd/lib/libskirthost.so skirt9_amd/lib/libpmc.so
+	$(CXX) $(CXXFLAGS) skirt9_amd/host/main.cpp -Lskirt9_amd/lib -lskirthost -lpmc -Wl,-rpath,'$$ORIGIN' -o $@
+
+# ---- test oracle (never part of `all`)
+oracle: oracle/_build/liboracle.so
+oracle/_build/liboracle.so: oracle/life_cycle.cpp $(wildcard include/*.h)
+	@mkdir -p oracle/_build
+	$(CXX) $(CXXFLAGS) -shared oracle/life_cycle.cpp -o $@
+
+host: skirt9_amd/lib/libskirthost.so
+clean:
+	rm -rf skirt9_amd/lib oracle/_build
+.PHONY: all oracle host clean

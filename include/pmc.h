@@ -1,0 +1,235 @@
+/* pmc.h -- C ABI of the MI355X photon-packet Monte Carlo engine ("pmc" = primary Monte Carlo).
+ *
+ * Drop-in boundary for SKIRT 9's primary-emission photon loop.  The reference has no FFI: the loop sits
+ * behind C++ virtuals in one process.  This header defines the seam a SKIRT maintainer would bind to; each
+ * entry point cites the reference code whose work it takes over (paths relative to the SKIRT 9 tree):
+ *
+ *   pmc_create        <- the read-only state the loop consumes after Simulation::setupSimulation():
+ *                        SpatialGrid (SKIRT/core/TreeSpatialGrid.cpp:23-78, CartesianSpatialGrid.cpp:14-28),
+ *                        MediumState number densities (MediumSystem.cpp:292-390), DustMix tables
+ *                        (DustMix.cpp:47-162), Configuration photon options (Configuration.cpp:105-109),
+ *                        SourceSystem launch data (SourceSystem.cpp:75-97), instruments
+ *                        (FrameInstrument.cpp:12-33) and FluxRecorder array shapes (FluxRecorder.cpp:185-300)
+ *   pmc_run_primary   <- MonteCarloSimulation::runPrimaryEmission's parallel->call(Npp, performLifeCycle)
+ *                        (MonteCarloSimulation.cpp:126-129, 538-613) + instrumentSystem()->flush() (:129)
+ *   pmc_download      <- the detector arrays FluxRecorder::calibrateAndWrite reads (FluxRecorder.cpp:484-493)
+ *   pmc_frames_device <- same arrays, as a device pointer, so that the caller can run the counterpart of
+ *                        ProcessManager::sumToRoot (SKIRT/mpi/ProcessManager.cpp:223-255) as ONE RCCL reduce
+ *   pmc_trace_ray     <- PathSegmentGenerator::start()/next() (TreeSpatialGrid.cpp:132-217,
+ *                        CartesianSpatialGrid.cpp:87-163): the (m, ds) sequence of one ray, for the bit-exact check
+ *   pmc_counters      <- no reference counterpart: counted cell visits / detector updates for the roofline
+ *
+ * Conventions: plain C, no exceptions cross the boundary; every function returns PMC_OK (0) or a negative
+ * status, and pmc_last_error() returns a human-readable message for the calling thread.  All input tables are
+ * host pointers owned by the caller; pmc_create copies what it needs to the device before returning.  One
+ * context per device; calls on one context must be serialised by the caller (the reference forbids recursive
+ * Parallel::call, SKIRT/core/Parallel.hpp).  All physical quantities are SI doubles, indices are int32.
+ */
+#ifndef PMC_H
+#define PMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMC_ABI_VERSION 1
+
+enum { PMC_OK = 0, PMC_ERR_INVALID = -1, PMC_ERR_UNSUPPORTED = -2, PMC_ERR_DEVICE = -3, PMC_ERR_NOMEM = -4 };
+
+/* ---------------------------------------------------------------- spatial grid ---- */
+
+enum { PMC_GRID_CARTESIAN = 1, PMC_GRID_OCTREE = 2 };
+
+/* walls in the reference's order (SKIRT/core/TreeNode.hpp enum Wall): BACK=-x, FRONT=+x, LEFT=-y, RIGHT=+y,
+   BOTTOM=-z, TOP=+z */
+enum { PMC_WALL_BACK = 0, PMC_WALL_FRONT, PMC_WALL_LEFT, PMC_WALL_RIGHT, PMC_WALL_BOTTOM, PMC_WALL_TOP };
+
+typedef struct pmc_grid
+{
+    int32_t kind;                 /* PMC_GRID_* */
+    double  xmin, ymin, zmin;     /* extent of the spatial domain (BoxSpatialGrid) */
+    double  xmax, ymax, zmax;
+    double  eps;                  /* 1e-12 * diagonal (TreeSpatialGrid.cpp:28, CartesianSpatialGrid.cpp:95) */
+    int32_t num_cells;
+
+    /* --- Cartesian (CartesianSpatialGrid.cpp:19-24): border arrays, m = k + nz*j + nz*ny*i */
+    int32_t nx, ny, nz;
+    const double* xv;             /* nx+1 */
+    const double* yv;             /* ny+1 */
+    const double* zv;             /* nz+1 */
+
+    /* --- Octree: the reference's node list in node-id order (TreeSpatialGrid.cpp:38-49), flattened.
+       node_box[6*id + {0..5}] = xmin,ymin,zmin,xmax,ymax,zmax exactly as the reference's TreeNode holds them;
+       node_first_child[id] = id of child 0 (children are 8 consecutive ids, OctTreeNode.cpp:22-33) or -1;
+       node_cell[id] = cell index m of a leaf or -1 (TreeSpatialGrid::_cellindexv);
+       neighbours of node id through wall w, in the reference's (sorted) list order (TreeNode.cpp:200-207):
+       nbr_list[ nbr_start[6*id+w] .. nbr_start[6*id+w+1] )  -- a CSR over 6*num_nodes rows. */
+    int32_t        num_nodes;
+    const double*  node_box;
+    const int32_t* node_level;
+    const int32_t* node_first_child;
+    const int32_t* node_cell;
+    const int32_t* nbr_start;     /* 6*num_nodes + 1 */
+    const int32_t* nbr_list;
+} pmc_grid;
+
+/* ---------------------------------------------------------------- medium ---- */
+
+typedef struct pmc_medium
+{
+    /* one dust medium with spatially constant cross sections (Configuration::hasSingleConstantSectionMedium) */
+    const double* number_density;   /* n[m], num_cells (MediumState, MediumSystem.cpp:868) */
+    /* DustMix tables (DustMix.cpp:93-98,112-162): index = locateClip(lambda_border, lambda) */
+    int32_t       num_lambda;
+    const double* lambda_border;    /* DustMix::_lambdav, num_lambda */
+    const double* sigma_ext;        /* num_lambda */
+    const double* sigma_sca;        /* num_lambda */
+    const double* asymmpar;         /* num_lambda, already clamped to +-0.999999 */
+} pmc_medium;
+
+typedef struct pmc_options
+{
+    int32_t force_scattering;       /* PhotonPacketOptions::forceScattering */
+    double  min_weight_reduction;   /* default 1e4 */
+    int32_t min_scatt_events;       /* default 0 */
+    double  path_length_bias;       /* default 0.5 */
+} pmc_options;
+
+/* ---------------------------------------------------------------- source ---- */
+
+enum { PMC_SOURCE_POINT = 1, PMC_SOURCE_SERSIC = 2, PMC_SOURCE_UNIFORM_BOX = 3 };
+enum { PMC_LAMBDA_OLIGO = 1, PMC_LAMBDA_TABULATED = 2 };
+enum { PMC_BIAS_NONE = 0, PMC_BIAS_LOG = 1, PMC_BIAS_LIN = 2 };
+
+typedef struct pmc_source
+{
+    int32_t kind;                   /* PMC_SOURCE_* (single source; SourceSystem with Ns = 1) */
+    double  position[3];            /* point source position */
+    double  reff;                   /* Sersic: effective radius; tables of SersicFunction (SersicFunction.cpp:13-77) */
+    int32_t sersic_n;               /*   number of table points (101) */
+    const double* sersic_s;         /*   _sv */
+    const double* sersic_M;         /*   _Mv (cumulative mass, normalised) */
+    double  box[6];                 /* uniform box source: xmin,ymin,zmin,xmax,ymax,zmax */
+
+    double  packet_luminosity;      /* L/Npp * Lv[h]/Wv[h]  (SourceSystem.cpp:96,105-106), before the lambda weight */
+
+    /* wavelength sampling (NormalizedSource.cpp:73-110) */
+    int32_t lambda_mode;            /* PMC_LAMBDA_* */
+    /* oligochromatic: xi = 1; 2 uniforms per packet; lambda = oligo_lambda[int(u*n)], weight oligo_weight[i] = s/b */
+    int32_t       num_oligo;
+    const double* oligo_lambda;
+    const double* oligo_weight;
+    /* panchromatic: SED tabulated for Random::cdfLogLog (Random.cpp:209-216): lambda, p (normalised), P (cumulative) */
+    double        lambda_bias;      /* xi of NormalizedSource (wavelengthBias, default 0.5); 0 => SED only */
+    int32_t       num_sed;
+    const double* sed_lambda;
+    const double* sed_p;
+    const double* sed_P;
+    int32_t       bias_kind;        /* PMC_BIAS_*: LogWavelengthDistribution / LinWavelengthDistribution */
+    double        bias_min, bias_max;
+} pmc_source;
+
+/* ---------------------------------------------------------------- instruments ---- */
+
+typedef struct pmc_instrument
+{
+    /* DistantInstrument / FrameInstrument (DistantInstrument.cpp:13-51, FrameInstrument.cpp:12-33) */
+    double  kobs[3];
+    double  costheta, sintheta, cosphi, sinphi, cosomega, sinomega;
+    int32_t nxp, nyp;
+    double  xpmin, xpsiz, ypmin, ypsiz;
+    int32_t same_observer_as_preceding;
+    /* FluxRecorder configuration (FluxRecorder.cpp:185-300) */
+    int32_t include_flux_density;        /* SED arrays */
+    int32_t include_surface_brightness;  /* IFU arrays */
+    int32_t record_components;           /* with a medium: Transparent, PrimaryDirect, PrimaryScattered (+levels) */
+    int32_t num_scattering_levels;
+    int32_t record_statistics;           /* sum of w^k, k = 0..4 */
+    double  redshift;
+    /* instrument wavelength grid (DisjointWavelengthGrid.cpp:320-345): bin = ellv[upper_bound(border, lambda)] */
+    int32_t        num_lambda;           /* number of bins */
+    int32_t        num_border;
+    const double*  border;
+    const int32_t* ellv;                 /* num_border + 1 */
+} pmc_instrument;
+
+/* Layout of one instrument's detector arrays inside the frame buffer (doubles).  Components c:
+   record_components ? {0:Transparent, 1:PrimaryDirect, 2:PrimaryScattered, 3+i: level i+1} : {0:Total}.
+   sed[c][ell]            at sed_offset  + c*num_lambda + ell
+   ifu[c][l + ell*npix]   at ifu_offset  + c*npix*num_lambda + l + ell*npix        (FluxRecorder.cpp:433)
+   wsed[k][ell]           at wsed_offset + k*num_lambda + ell                       k = 0..4
+   wifu[k][l + ell*npix]  at wifu_offset + k*npix*num_lambda + ...                  (FluxRecorder.cpp:962-1014)
+   an offset of -1 means "array not present". */
+typedef struct pmc_frame_layout
+{
+    int64_t num_components;
+    int64_t npix;
+    int64_t num_lambda;
+    int64_t sed_offset, ifu_offset, wsed_offset, wifu_offset;
+    int64_t end_offset;
+} pmc_frame_layout;
+
+typedef struct pmc_scene
+{
+    int32_t abi_version;            /* PMC_ABI_VERSION */
+    pmc_grid    grid;
+    pmc_medium  medium;
+    pmc_options options;
+    pmc_source  source;
+    int32_t     num_instruments;
+    const pmc_instrument* instruments;
+} pmc_scene;
+
+/* counted work, accumulated over all pmc_run_primary calls since create/reset (roofline inputs) */
+typedef struct pmc_counter_values
+{
+    uint64_t histories;        /* packets launched */
+    uint64_t paths;            /* grid walks started (forced-scattering paths + peel-off paths) */
+    uint64_t cell_visits;      /* V: segments with m >= 0 over every path walked */
+    uint64_t detector_updates; /* U: f64 atomic adds into flux/statistics arrays */
+    uint64_t scatterings;      /* scattering events simulated */
+    uint64_t stat_overflows;   /* histories whose per-history contribution list overflowed (should be 0) */
+} pmc_counter_values;
+
+typedef struct pmc_ctx pmc_ctx;
+
+/* --- pure host helpers (no device needed) */
+int  pmc_abi_version(void);
+const char* pmc_last_error(void);
+/* computes the layout of instrument i and returns the total number of doubles of the whole frame buffer */
+int64_t pmc_frame_layout_of(const pmc_scene* scene, int32_t instrument, pmc_frame_layout* out);
+
+/* --- device API */
+int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out);
+void pmc_destroy(pmc_ctx* ctx);
+/* Use caller-owned DEVICE memory (num_doubles f64, zero-initialised by the caller) for the frames instead of the
+   context's own allocation -- e.g. a torch tensor, so that torch.distributed can reduce it over RCCL. */
+int pmc_bind_frames(pmc_ctx* ctx, double* device_ptr, int64_t num_doubles);
+int pmc_clear_frames(pmc_ctx* ctx);
+/* Launch histories [first, first+count) on the context's stream; results are ACCUMULATED into the frames.
+   Asynchronous: returns after the launch; pmc_sync / pmc_download wait.  The RNG stream of a history depends only
+   on (seed, history index), so any partition of [0,Npp) over calls and devices gives the same result up to the
+   summation order of the floating-point atomics. */
+int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed);
+int pmc_sync(pmc_ctx* ctx);
+int pmc_download(pmc_ctx* ctx, double* host_frames, int64_t num_doubles);
+double* pmc_frames_device(pmc_ctx* ctx);
+int64_t pmc_frames_size(pmc_ctx* ctx);
+/* duration in milliseconds of the most recent pmc_run_primary kernel, measured with HIP events on the context's
+   stream (valid after pmc_sync) */
+int pmc_last_kernel_ms(pmc_ctx* ctx, float* ms);
+int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out);
+int pmc_reset_counters(pmc_ctx* ctx);
+/* Walk one ray on the device with the same traversal code the photon loop uses; k is normalised by the caller.
+   Writes up to cap segments (cell index m or -1, length ds) and the number found to *n. */
+int pmc_trace_ray(pmc_ctx* ctx, const double r[3], const double k[3], int32_t* m, double* ds, int32_t cap, int32_t* n);
+/* tuning knobs (0 = default): threads per workgroup, workgroups; returns PMC_OK */
+int pmc_set_launch(pmc_ctx* ctx, int32_t block, int32_t grid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

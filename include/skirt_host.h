@@ -1,0 +1,43 @@
+/* skirt_host.h -- C entry points of the host model layer (libskirthost.so).
+ *
+ * The host layer reads an unchanged SKIRT .ski file, performs the reference's setup for the classes the
+ * primary-emission path supports (grid construction, density sampling, dust tables, source tables, instruments;
+ * SKIRT/core/MonteCarloSimulation.cpp:20-37 setupSimulation) and flattens the result into the pmc_scene of
+ * pmc.h.  After the photon loop it calibrates the detector arrays and writes the reference's output files
+ * (FluxRecorder::calibrateAndWrite, SKIRT/core/FluxRecorder.cpp:484-846).  It contains NO photon loop.
+ */
+#ifndef SKIRT_HOST_H
+#define SKIRT_HOST_H
+
+#include "pmc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct skh_simulation skh_simulation;
+
+const char* skh_last_error(void);
+/* XmlHierarchyCreator::readFile: parse the ski file; NULL on error */
+skh_simulation* skh_load(const char* ski_path);
+void skh_free(skh_simulation* sim);
+/* overrides applied before skh_setup */
+int skh_set_num_packets(skh_simulation* sim, uint64_t n);
+int skh_set_tree_topology_file(skh_simulation* sim, const char* treetop_path);
+/* Simulation::setupSimulation */
+int skh_setup(skh_simulation* sim);
+/* valid after skh_setup, owned by the simulation */
+const pmc_scene* skh_scene(const skh_simulation* sim);
+uint64_t skh_num_packets(const skh_simulation* sim);
+int32_t  skh_seed(const skh_simulation* sim);
+uint64_t skh_setup_draws(const skh_simulation* sim);
+int64_t  skh_frame_size(const skh_simulation* sim);
+int skh_frame_layout(const skh_simulation* sim, int32_t instrument, pmc_frame_layout* out);
+/* calibrates `frames` in place and writes <prefix>_<instrument>_*.fits / _sed.dat / _sedstats.dat into outdir */
+int skh_write(const skh_simulation* sim, double* frames, const char* outdir);
+int skh_summary(const skh_simulation* sim, char* buffer, int32_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,138 @@
+"""ctypes binding of the host model layer (libskirthost.so, include/skirt_host.h).
+
+The host layer reads an unchanged SKIRT ``.ski`` file, runs the reference's setup for the supported classes and
+exposes the flattened ``pmc_scene`` that the HIP engine (``skirt9_amd.engine``) consumes; after the photon loop it
+calibrates the detector arrays and writes SKIRT's output files.  Mirrors the call sequence of
+``SkirtCommandLineHandler::doSimulation`` (SKIRT/main/SkirtCommandLineHandler.cpp:295-372):
+``load -> setup -> [engine] -> write``.
+"""
+import ctypes as C
+import os
+
+_LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+
+
+class FrameLayout(C.Structure):
+    """pmc_frame_layout (include/pmc.h)"""
+    _fields_ = [("num_components", C.c_int64), ("npix", C.c_int64), ("num_lambda", C.c_int64),
+                ("sed_offset", C.c_int64), ("ifu_offset", C.c_int64), ("wsed_offset", C.c_int64),
+                ("wifu_offset", C.c_int64), ("end_offset", C.c_int64)]
+
+
+class CounterValues(C.Structure):
+    """pmc_counter_values (include/pmc.h)"""
+    _fields_ = [("histories", C.c_uint64), ("paths", C.c_uint64), ("cell_visits", C.c_uint64),
+                ("detector_updates", C.c_uint64), ("scatterings", C.c_uint64), ("stat_overflows", C.c_uint64)]
+
+    def as_dict(self):
+        return {name: int(getattr(self, name)) for name, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_LIBDIR, "libskirthost.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make` (or __graft_entry__.build()) first")
+        L = C.CDLL(path)
+        L.skh_last_error.restype = C.c_char_p
+        L.skh_load.restype = C.c_void_p
+        L.skh_load.argtypes = [C.c_char_p]
+        L.skh_free.argtypes = [C.c_void_p]
+        L.skh_set_num_packets.argtypes = [C.c_void_p, C.c_uint64]
+        L.skh_set_tree_topology_file.argtypes = [C.c_void_p, C.c_char_p]
+        L.skh_setup.argtypes = [C.c_void_p]
+        L.skh_scene.restype = C.c_void_p
+        L.skh_scene.argtypes = [C.c_void_p]
+        L.skh_num_packets.restype = C.c_uint64
+        L.skh_num_packets.argtypes = [C.c_void_p]
+        L.skh_seed.restype = C.c_int32
+        L.skh_seed.argtypes = [C.c_void_p]
+        L.skh_setup_draws.restype = C.c_uint64
+        L.skh_setup_draws.argtypes = [C.c_void_p]
+        L.skh_frame_size.restype = C.c_int64
+        L.skh_frame_size.argtypes = [C.c_void_p]
+        L.skh_frame_layout.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FrameLayout)]
+        L.skh_write.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+        L.skh_summary.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+        _lib = L
+    return _lib
+
+
+class Simulation:
+    """A MonteCarloSimulation constructed from a ski file."""
+
+    def __init__(self, ski_path, num_packets=None, tree_topology=None):
+        L = lib()
+        self._h = L.skh_load(os.fsencode(ski_path))
+        if not self._h:
+            raise RuntimeError(L.skh_last_error().decode())
+        if num_packets is not None:
+            L.skh_set_num_packets(self._h, int(num_packets))
+        if tree_topology is not None:
+            if L.skh_set_tree_topology_file(self._h, os.fsencode(tree_topology)) != 0:
+                raise RuntimeError(L.skh_last_error().decode())
+        self._setup = False
+
+    def setup(self):
+        if lib().skh_setup(self._h) != 0:
+            raise RuntimeError(lib().skh_last_error().decode())
+        self._setup = True
+        return self
+
+    def close(self):
+        if self._h:
+            lib().skh_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def scene(self):
+        """address of the pmc_scene (valid while this object lives)"""
+        assert self._setup, "call setup() first"
+        return lib().skh_scene(self._h)
+
+    @property
+    def num_packets(self):
+        return int(lib().skh_num_packets(self._h))
+
+    @property
+    def seed(self):
+        return int(lib().skh_seed(self._h))
+
+    @property
+    def setup_draws(self):
+        return int(lib().skh_setup_draws(self._h))
+
+    @property
+    def frame_size(self):
+        return int(lib().skh_frame_size(self._h))
+
+    def layout(self, instrument=0):
+        out = FrameLayout()
+        if lib().skh_frame_layout(self._h, instrument, C.byref(out)) != 0:
+            raise IndexError(instrument)
+        return out
+
+    def summary(self):
+        buf = C.create_string_buffer(2048)
+        lib().skh_summary(self._h, buf, len(buf))
+        return buf.value.decode()
+
+    def write(self, frames, outdir):
+        """calibrate a COPY of the detector arrays (numpy float64) and write the output files into outdir"""
+        import numpy as np
+        data = np.ascontiguousarray(frames, dtype=np.float64).copy()
+        assert data.size == self.frame_size
+        os.makedirs(outdir, exist_ok=True)
+        if lib().skh_write(self._h, data.ctypes.data_as(C.c_void_p), os.fsencode(outdir)) != 0:
+            raise RuntimeError(lib().skh_last_error().decode())
+        return data

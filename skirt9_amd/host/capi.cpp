@@ -1,0 +1,156 @@
+// capi.cpp -- C entry points of the host model layer (libskirthost.so), for ctypes and for the command line driver.
+// See include/skirt_host.h for the declarations.
+
+#include "../../include/skirt_host.h"
+#include "simulation.hpp"
+#include <cstring>
+#include <fstream>
+
+namespace
+{
+    thread_local std::string t_error;
+    int fail(const std::exception& e)
+    {
+        t_error = e.what();
+        return -1;
+    }
+}
+
+struct skh_simulation
+{
+    std::unique_ptr<skh::Simulation> sim;
+};
+
+extern "C" {
+
+const char* skh_last_error(void)
+{
+    return t_error.c_str();
+}
+
+skh_simulation* skh_load(const char* ski_path)
+{
+    try
+    {
+        auto h = new skh_simulation();
+        h->sim = skh::Simulation::fromFile(ski_path);
+        return h;
+    }
+    catch (const std::exception& e)
+    {
+        fail(e);
+        return nullptr;
+    }
+}
+
+void skh_free(skh_simulation* h)
+{
+    delete h;
+}
+
+int skh_set_num_packets(skh_simulation* h, uint64_t n)
+{
+    h->sim->setNumPackets(n);
+    return 0;
+}
+
+int skh_set_tree_topology_file(skh_simulation* h, const char* path)
+{
+    try
+    {
+        // TreeSpatialGridTopologyProbe format (TreeSpatialGrid.cpp:225-251): comment lines, the number of children
+        // of the root, then one "1"/"0" per node in depth-first order
+        std::ifstream in(path);
+        if (!in) throw std::runtime_error(std::string("cannot open tree topology file ") + path);
+        std::vector<char> topology;
+        std::string line;
+        bool first = true;
+        while (std::getline(in, line))
+        {
+            if (line.empty() || line[0] == '#') continue;
+            if (first)
+            {
+                first = false;
+                if (std::stoi(line) != 8 && std::stoi(line) != 0) throw std::runtime_error("topology is not an octree");
+                continue;
+            }
+            topology.push_back(line[0] == '1');
+        }
+        h->sim->setTreeTopology(std::move(topology));
+        return 0;
+    }
+    catch (const std::exception& e)
+    {
+        return fail(e);
+    }
+}
+
+int skh_setup(skh_simulation* h)
+{
+    try
+    {
+        h->sim->setup();
+        return 0;
+    }
+    catch (const std::exception& e)
+    {
+        return fail(e);
+    }
+}
+
+const pmc_scene* skh_scene(const skh_simulation* h)
+{
+    return &h->sim->scene();
+}
+
+uint64_t skh_num_packets(const skh_simulation* h)
+{
+    return h->sim->numPackets();
+}
+
+int32_t skh_seed(const skh_simulation* h)
+{
+    return h->sim->seed();
+}
+
+uint64_t skh_setup_draws(const skh_simulation* h)
+{
+    return h->sim->setupDraws();
+}
+
+int64_t skh_frame_size(const skh_simulation* h)
+{
+    return h->sim->frameSize();
+}
+
+int skh_frame_layout(const skh_simulation* h, int32_t instrument, pmc_frame_layout* out)
+{
+    if (instrument < 0 || instrument >= h->sim->numInstruments()) return -1;
+    *out = h->sim->layout(instrument);
+    return 0;
+}
+
+int skh_write(const skh_simulation* h, double* frames, const char* outdir)
+{
+    try
+    {
+        h->sim->write(frames, outdir);
+        return 0;
+    }
+    catch (const std::exception& e)
+    {
+        return fail(e);
+    }
+}
+
+int skh_summary(const skh_simulation* h, char* buffer, int32_t capacity)
+{
+    std::string s = h->sim->summary();
+    if (capacity > 0)
+    {
+        std::strncpy(buffer, s.c_str(), capacity - 1);
+        buffer[capacity - 1] = 0;
+    }
+    return static_cast<int>(s.size());
+}
+}

@@ -1,0 +1,287 @@
+// model.hpp -- host model layer: the SKIRT-equivalent objects a ski file describes, for the classes the
+// primary-emission path supports, and their flattening into the POD tables of include/pmc.h.
+//
+// Class names and semantics follow the reference (SKIRT/core); each implementation cites the code it restates.
+// Unsupported ski classes raise a std::runtime_error naming the class ("not supported on the MI355X path").
+#ifndef SKH_MODEL_HPP
+#define SKH_MODEL_HPP
+
+#include "../../include/pmc.h"
+#include "mathutil.hpp"
+#include "xml.hpp"
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace skh
+{
+    // ---------------------------------------------------------------- units selected in the ski file
+
+    struct OutputUnits
+    {
+        std::string system{"ExtragalacticUnits"};  // SIUnits | StellarUnits | ExtragalacticUnits
+        std::string wavelengthStyle{"Wavelength"};
+        std::string fluxStyle{"Frequency"};  // Neutral | Wavelength | Frequency
+        double out(const std::string& qty, double value) const;
+        std::string unit(const std::string& qty) const;
+        // Units.cpp:111-160, 529-609
+        std::string swavelength() const { return "lambda"; }
+        std::string uwavelength() const { return unit("wavelength"); }
+        double owavelength(double lambda) const { return out("wavelength", lambda); }
+        std::string sfluxdensity() const;
+        std::string ufluxdensity() const;
+        double ofluxdensity(double lambda, double Flambda) const;
+        std::string usurfacebrightness() const;
+        double osurfacebrightness(double lambda, double flambda) const;
+    };
+
+    // ---------------------------------------------------------------- geometries
+
+    class Geometry
+    {
+    public:
+        virtual ~Geometry() {}
+        virtual std::string type() const = 0;
+        virtual double density(Vec3 r) const = 0;
+        virtual double SigmaX() const = 0;
+        virtual double SigmaY() const = 0;
+        virtual double SigmaZ() const = 0;
+    };
+
+    // SKIRT/utils/SersicFunction.cpp:13-101
+    class SersicFunction
+    {
+    public:
+        explicit SersicFunction(double n);
+        double operator()(double s) const;
+        double inverseMass(double M) const;
+        const Array& sv() const { return _sv; }
+        const Array& Mv() const { return _Mv; }
+
+    private:
+        Array _sv, _Sv, _Mv;
+    };
+
+    class UniformBoxGeometry : public Geometry
+    {
+    public:
+        explicit UniformBoxGeometry(const Box& box);
+        std::string type() const override { return "UniformBoxGeometry"; }
+        double density(Vec3 r) const override;
+        double SigmaX() const override;
+        double SigmaY() const override;
+        double SigmaZ() const override;
+        const Box& box() const { return _box; }
+
+    private:
+        Box _box;
+        double _rho{0};
+    };
+
+    class ExpDiskGeometry : public Geometry
+    {
+    public:
+        ExpDiskGeometry(double hR, double hz, double Rmin, double Rmax, double zmax);
+        std::string type() const override { return "ExpDiskGeometry"; }
+        double density(Vec3 r) const override;
+        double SigmaX() const override { return 2.0 * SigmaR(); }
+        double SigmaY() const override { return 2.0 * SigmaR(); }
+        double SigmaZ() const override;
+        double SigmaR() const;
+
+    private:
+        double _hR, _hz, _Rmin, _Rmax, _zmax, _rho0;
+    };
+
+    class SersicGeometry : public Geometry
+    {
+    public:
+        SersicGeometry(double reff, double n);
+        std::string type() const override { return "SersicGeometry"; }
+        double density(Vec3 r) const override;
+        double SigmaX() const override { return 2.0 * Sigmar(); }
+        double SigmaY() const override { return 2.0 * Sigmar(); }
+        double SigmaZ() const override { return 2.0 * Sigmar(); }
+        double Sigmar() const;
+        double reff() const { return _reff; }
+        const SersicFunction& function() const { return *_function; }
+
+    private:
+        double _reff, _n, _rho0, _b;
+        std::unique_ptr<SersicFunction> _function;
+    };
+
+    class PlummerGeometry : public Geometry
+    {
+    public:
+        explicit PlummerGeometry(double c);
+        std::string type() const override { return "PlummerGeometry"; }
+        double density(Vec3 r) const override;
+        double SigmaX() const override { return 2.0 * Sigmar(); }
+        double SigmaY() const override { return 2.0 * Sigmar(); }
+        double SigmaZ() const override { return 2.0 * Sigmar(); }
+        double Sigmar() const;
+
+    private:
+        double _c, _rho0;
+    };
+
+    // ---------------------------------------------------------------- dust mix (tabulated mean properties)
+
+    // DustMix tables for a TabulatedDustMix subclass (MeanListDustMix / MeanFileDustMix):
+    // SKIRT/core/DustMix.cpp:47-162, TabulatedDustMix.cpp:12-45, MeanListDustMix.cpp:12-27
+    class DustMix
+    {
+    public:
+        std::string typeName;
+        Array inLambda, inKappaExt, inAlbedo, inAsymmpar;  // as configured
+        double mu{1.5e-29};
+        // built by setup()
+        Array lambdaSample;  // sampling wavelengths (DustMix.cpp local lambdav)
+        Array lambdaBorder;  // DustMix::_lambdav (shifted borders used by indexForLambda)
+        Array sigmaAbs, sigmaSca, sigmaExt, asymmpar;
+
+        void setup(double rangeMin, double rangeMax, const std::vector<double>& simulationWavelengths);
+        int indexForLambda(double lambda) const { return nr::locateClip(lambdaBorder, lambda); }
+        double sectionExt(double lambda) const { return sigmaExt[indexForLambda(lambda)]; }
+        double sectionSca(double lambda) const { return sigmaSca[indexForLambda(lambda)]; }
+        double mass() const { return mu; }
+    };
+
+    // ---------------------------------------------------------------- medium
+
+    // GeometricMedium with OpticalDepth/Mass/Number material normalisation
+    // SKIRT/core/GeometricMedium.cpp:13-18,128-131; OpticalDepthMaterialNormalization.cpp:13-27
+    class GeometricMedium
+    {
+    public:
+        std::unique_ptr<Geometry> geometry;
+        std::unique_ptr<DustMix> mix;
+        std::string normType;  // OpticalDepthMaterialNormalization | MassMaterialNormalization | NumberMaterialNormalization
+        char normAxis{'Z'};
+        double normWavelength{0.55e-6};
+        double normOpticalDepth{0};
+        double normMass{0};
+        double normNumber{0};
+        double number{0}, mass{0};  // results of setup()
+
+        void setup();
+        double numberDensity(Vec3 r) const { return number * geometry->density(r); }
+        double massDensity(Vec3 r) const { return mass * geometry->density(r); }
+    };
+
+    // ---------------------------------------------------------------- spatial grids
+
+    class SpatialGrid
+    {
+    public:
+        virtual ~SpatialGrid() {}
+        Box extent;
+        virtual int numCells() const = 0;
+        virtual Box cellBox(int m) const = 0;
+        virtual void fill(pmc_grid& g) const = 0;
+    };
+
+    // CartesianSpatialGrid with LinMesh axes (CartesianSpatialGrid.cpp:14-28, LinMesh.cpp:11-16)
+    class CartesianSpatialGrid : public SpatialGrid
+    {
+    public:
+        int nx{0}, ny{0}, nz{0};
+        Array xv, yv, zv;
+        void setup();
+        int numCells() const override { return nx * ny * nz; }
+        Box cellBox(int m) const override;
+        void fill(pmc_grid& g) const override;
+    };
+
+    // PolicyTreeSpatialGrid (treeType OctTree) with DensityTreePolicy
+    // TreeSpatialGrid.cpp:23-78, TreeNode.cpp, OctTreeNode.cpp:22-138, DensityTreePolicy.cpp:117-309
+    class OctreeSpatialGrid : public SpatialGrid
+    {
+    public:
+        // policy configuration
+        int minLevel{3}, maxLevel{7};
+        double maxDustFraction{1e-6}, maxDustOpticalDepth{0}, policyWavelength{0.55e-6}, maxDustDensityDispersion{0};
+
+        struct Node
+        {
+            Box box;
+            int level{0};
+            int parent{-1};
+            int firstChild{-1};
+            std::vector<int> neighbors[6];
+        };
+        std::vector<Node> nodes;
+        std::vector<int> cellIndexOfNode;  // _cellindexv
+        std::vector<int> nodeOfCell;       // _idv
+        // flattened (built by setup)
+        std::vector<double> flatBox;
+        std::vector<int32_t> flatLevel, flatFirstChild, flatCell, flatNbrStart, flatNbrList;
+
+        // builds the tree; consumes the random stream exactly like DensityTreePolicy::constructTree at one thread
+        void setup(const GeometricMedium& medium, int numDensitySamples, Random& random);
+        // builds the tree from a topology stream ("1"/"0" per node, depth first; TreeSpatialGrid.cpp:225-251) --
+        // the node ids are then assigned breadth-first as the policy would have done for the same topology
+        void setupFromTopology(const std::vector<char>& topology);
+        int numCells() const override { return static_cast<int>(nodeOfCell.size()); }
+        Box cellBox(int m) const override { return nodes[nodeOfCell[m]].box; }
+        void fill(pmc_grid& g) const override;
+
+    private:
+        void subdivide(int id);
+        void finish();
+    };
+
+    // ---------------------------------------------------------------- source
+
+    struct SourceModel
+    {
+        std::string type;  // PointSource | GeometricSource
+        Vec3 position;
+        std::unique_ptr<Geometry> geometry;
+        double sourceWeight{1.};
+        double wavelengthBias{0.5};
+        std::string biasDistType{"DefaultWavelengthDistribution"};
+        double biasMin{0}, biasMax{0};
+        // BlackBodySED
+        double temperature{5000.};
+        // IntegratedLuminosityNormalization
+        std::string normRange{"Source"};
+        double normMinWavelength{0.09e-6}, normMaxWavelength{100e-6}, integratedLuminosity{0};
+    };
+
+    // ---------------------------------------------------------------- wavelength grid (disjoint bins)
+
+    // DisjointWavelengthGrid.cpp:22-135,300-345
+    struct WavelengthGrid
+    {
+        Array lambdav, lambdaleftv, lambdarightv, dlambdav, borderv;
+        std::vector<int32_t> ellv;
+        void setWavelengthRange(Array lambda, bool logScale);                              // Log/Lin/List grids
+        void setWavelengthBins(Array lambda, double relativeHalfWidth, bool constantWidth);  // Oligo grid
+        int numBins() const { return static_cast<int>(lambdav.size()); }
+        double wavelength(int ell) const { return lambdav[ell]; }
+        double effectiveWidth(int ell) const { return dlambdav[ell]; }
+        double rangeMin() const { return lambdaleftv.front(); }
+        double rangeMax() const { return lambdarightv.back(); }
+        int bin(double lambda) const;
+    };
+
+    // ---------------------------------------------------------------- instruments
+
+    struct InstrumentModel
+    {
+        std::string type;  // FrameInstrument | FullInstrument
+        std::string name;
+        double distance{0}, inclination{0}, azimuth{0}, roll{0};
+        double fieldOfViewX{0}, fieldOfViewY{0}, centerX{0}, centerY{0};
+        int numPixelsX{250}, numPixelsY{250};
+        bool recordComponents{false}, recordPolarization{false}, recordStatistics{false};
+        int numScatteringLevels{0};
+        std::unique_ptr<WavelengthGrid> ownGrid;  // instrument-specific grid (panchromatic only)
+        const WavelengthGrid* grid{nullptr};      // the grid in effect
+        bool sameObserverAsPreceding{false};
+    };
+}
+
+#endif

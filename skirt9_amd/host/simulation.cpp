@@ -1,0 +1,672 @@
+// simulation.cpp -- ski parsing, setup and scene flattening (see simulation.hpp).  Citations: SKIRT 9 tree.
+
+#include "simulation.hpp"
+#include "../../include/pmc_layout.h"
+#include "units.hpp"
+#include <cstring>
+#include <fstream>
+#include <set>
+#include <sstream>
+
+namespace skh
+{
+    namespace
+    {
+        [[noreturn]] void unsupported(const std::string& what)
+        {
+            throw std::runtime_error("ski: " + what + " is not supported on the MI355X primary-emission path");
+        }
+
+        // attribute access with the reference's defaults (ATTRIBUTE_DEFAULT_VALUE in the class headers)
+        struct Reader
+        {
+            std::string unitSystem;
+            double quantity(const XmlElement& e, const char* key, const char* qty, const char* fallback = nullptr) const
+            {
+                if (e.has(key)) return parseQuantity(e.attr(key), qty, unitSystem);
+                if (!fallback)
+                    throw std::runtime_error("ski: <" + e.name + "> lacks the required attribute '" + key + "'");
+                return parseQuantity(fallback, qty, unitSystem);
+            }
+            double number(const XmlElement& e, const char* key, const char* fallback = nullptr) const
+            {
+                return quantity(e, key, "", fallback);
+            }
+            int integer(const XmlElement& e, const char* key, int fallback) const
+            {
+                if (!e.has(key)) return fallback;
+                return std::stoi(squeeze(e.attr(key)));
+            }
+            bool boolean(const XmlElement& e, const char* key, bool fallback) const
+            {
+                if (!e.has(key)) return fallback;
+                std::string v = squeeze(e.attr(key));
+                if (v == "true" || v == "True" || v == "1" || v == "yes") return true;
+                if (v == "false" || v == "False" || v == "0" || v == "no") return false;
+                throw std::runtime_error("ski: invalid boolean '" + v + "' for attribute " + key);
+            }
+            std::vector<double> list(const XmlElement& e, const char* key, const char* qty, const char* fallback) const
+            {
+                return parseQuantityList(e.has(key) ? e.attr(key) : std::string(fallback), qty, unitSystem);
+            }
+        };
+
+        std::unique_ptr<Geometry> makeGeometry(const XmlElement& e, const Reader& rd)
+        {
+            if (e.name == "UniformBoxGeometry")
+                return std::make_unique<UniformBoxGeometry>(
+                    Box(rd.quantity(e, "minX", "length"), rd.quantity(e, "minY", "length"), rd.quantity(e, "minZ", "length"),
+                        rd.quantity(e, "maxX", "length"), rd.quantity(e, "maxY", "length"), rd.quantity(e, "maxZ", "length")));
+            if (e.name == "ExpDiskGeometry")
+                return std::make_unique<ExpDiskGeometry>(rd.quantity(e, "scaleLength", "length"),
+                                                         rd.quantity(e, "scaleHeight", "length"),
+                                                         rd.quantity(e, "minRadius", "length", "0"),
+                                                         rd.quantity(e, "maxRadius", "length", "0"),
+                                                         rd.quantity(e, "maxZ", "length", "0"));
+            if (e.name == "SersicGeometry")
+                return std::make_unique<SersicGeometry>(rd.quantity(e, "effectiveRadius", "length"), rd.number(e, "index", "1"));
+            if (e.name == "PlummerGeometry") return std::make_unique<PlummerGeometry>(rd.quantity(e, "scaleLength", "length"));
+            unsupported("geometry " + e.name);
+        }
+
+        std::unique_ptr<WavelengthGrid> makeWavelengthGrid(const XmlElement& e, const Reader& rd)
+        {
+            auto grid = std::make_unique<WavelengthGrid>();
+            if (e.name == "LogWavelengthGrid")
+            {
+                // LogWavelengthGrid.cpp:12-24
+                double lo = rd.quantity(e, "minWavelength", "wavelength");
+                double hi = rd.quantity(e, "maxWavelength", "wavelength");
+                int n = rd.integer(e, "numWavelengths", 25);
+                if (hi <= lo) throw std::runtime_error("the longest wavelength should be larger than the shortest");
+                Array lambdav;
+                nr::logGrid(lambdav, lo, hi, n - 1);
+                grid->setWavelengthRange(lambdav, true);
+            }
+            else if (e.name == "LinWavelengthGrid")
+            {
+                double lo = rd.quantity(e, "minWavelength", "wavelength");
+                double hi = rd.quantity(e, "maxWavelength", "wavelength");
+                int n = rd.integer(e, "numWavelengths", 25);
+                if (hi <= lo) throw std::runtime_error("the longest wavelength should be larger than the shortest");
+                Array lambdav;
+                nr::linearGrid(lambdav, lo, hi, n - 1);
+                grid->setWavelengthRange(lambdav, false);
+            }
+            else if (e.name == "ListWavelengthGrid")
+            {
+                Array lambdav = rd.list(e, "wavelengths", "wavelength", "");
+                double rhw = rd.number(e, "relativeHalfWidth", "0");
+                if (rhw)
+                    grid->setWavelengthBins(lambdav, rhw, false);
+                else
+                    grid->setWavelengthRange(lambdav, rd.boolean(e, "log", true));
+            }
+            else
+                unsupported("wavelength grid " + e.name);
+            return grid;
+        }
+    }
+
+    // ================================================================ construction
+
+    std::unique_ptr<Simulation> Simulation::fromFile(const std::string& path)
+    {
+        std::ifstream in(path, std::ios::binary);
+        if (!in) throw std::runtime_error("Cannot open ski file " + path);
+        std::stringstream ss;
+        ss << in.rdbuf();
+        // output prefix = file name without directory and extension (StringUtils::filenameBase)
+        std::string base = path;
+        size_t slash = base.find_last_of('/');
+        if (slash != std::string::npos) base = base.substr(slash + 1);
+        size_t dot = base.find_last_of('.');
+        if (dot != std::string::npos) base = base.substr(0, dot);
+        return fromString(ss.str(), base);
+    }
+
+    std::unique_ptr<Simulation> Simulation::fromString(const std::string& text, const std::string& prefix)
+    {
+        XmlParser parser(text);
+        auto root = parser.parseDocument();
+        std::unique_ptr<Simulation> sim(new Simulation());
+        sim->_prefix = prefix;
+        sim->parse(*root);
+        return sim;
+    }
+
+    void Simulation::parse(const XmlElement& root)
+    {
+        if (root.name != "skirt-simulation-hierarchy" || root.attr("type", "") != "MonteCarloSimulation")
+            throw std::runtime_error("ski: the root element is not a skirt-simulation-hierarchy of type MonteCarloSimulation");
+        if (root.children.empty() || root.children[0]->name != "MonteCarloSimulation")
+            throw std::runtime_error("ski: missing MonteCarloSimulation element");
+        const XmlElement& sim = *root.children[0];
+
+        // units first: they determine the default unit of unit-less attribute values
+        Reader rd;
+        rd.unitSystem = "ExtragalacticUnits";
+        if (const XmlElement* u = sim.item("units"))
+        {
+            if (!unitTable().hasSystem(u->name)) unsupported("unit system " + u->name);
+            _units.system = rd.unitSystem = u->name;
+            _units.wavelengthStyle = u->attr("wavelengthOutputStyle", "Wavelength");
+            _units.fluxStyle = u->attr("fluxOutputStyle", "Frequency");
+            if (_units.wavelengthStyle != "Wavelength") unsupported("wavelengthOutputStyle " + _units.wavelengthStyle);
+            if (_units.fluxStyle != "Frequency" && _units.fluxStyle != "Wavelength" && _units.fluxStyle != "Neutral")
+                unsupported("fluxOutputStyle " + _units.fluxStyle);
+        }
+
+        std::string mode = sim.attr("simulationMode", "ExtinctionOnly");
+        if (mode == "OligoExtinctionOnly")
+            _oligo = true;
+        else if (mode == "ExtinctionOnly")
+            _oligo = false;
+        else
+            unsupported("simulationMode " + mode);
+        if (rd.boolean(sim, "iteratePrimaryEmission", false)) unsupported("iteratePrimaryEmission");
+        _numPackets = static_cast<uint64_t>(rd.number(sim, "numPackets", "1e6"));  // Configuration.cpp:50
+
+        if (const XmlElement* r = sim.item("random"))
+        {
+            if (r->name != "Random") unsupported("random generator " + r->name);
+            _seed = rd.integer(*r, "seed", 0);
+        }
+        if (const XmlElement* c = sim.item("cosmology"))
+            if (c->name != "LocalUniverseCosmology") unsupported("cosmology " + c->name);
+
+        // ---- source system (SourceSystem.hpp properties)
+        const XmlElement* ss = sim.item("sourceSystem");
+        if (!ss) throw std::runtime_error("ski: missing sourceSystem");
+        _ssMinWavelength = rd.quantity(*ss, "minWavelength", "wavelength", "0.09 micron");
+        _ssMaxWavelength = rd.quantity(*ss, "maxWavelength", "wavelength", "100 micron");
+        _oligoWavelengths = rd.list(*ss, "wavelengths", "wavelength", "0.55 micron");
+        _sourceBias = rd.number(*ss, "sourceBias", "0.5");
+        auto sources = ss->items("sources");
+        if (sources.size() != 1) unsupported("a source system with " + std::to_string(sources.size()) + " sources");
+        const XmlElement& src = *sources[0];
+        _source.type = src.name;
+        _source.sourceWeight = rd.number(src, "sourceWeight", "1");
+        _source.wavelengthBias = rd.number(src, "wavelengthBias", "0.5");
+        if (src.name == "PointSource")
+        {
+            _source.position = Vec3{rd.quantity(src, "positionX", "length", "0"), rd.quantity(src, "positionY", "length", "0"),
+                                    rd.quantity(src, "positionZ", "length", "0")};
+            bool moving = rd.quantity(src, "velocityX", "velocity", "0") || rd.quantity(src, "velocityY", "velocity", "0")
+                          || rd.quantity(src, "velocityZ", "velocity", "0");
+            if (moving && !_oligo) unsupported("a source with a bulk velocity");
+            if (const XmlElement* ad = src.item("angularDistribution"))
+                if (ad->name != "IsotropicAngularDistribution") unsupported("angular distribution " + ad->name);
+            if (const XmlElement* pp = src.item("polarizationProfile"))
+                if (pp->name != "NoPolarizationProfile") unsupported("polarization profile " + pp->name);
+        }
+        else if (src.name == "GeometricSource")
+        {
+            const XmlElement* g = src.item("geometry");
+            if (!g) throw std::runtime_error("ski: GeometricSource lacks a geometry");
+            if (g->name != "SersicGeometry" && g->name != "UniformBoxGeometry") unsupported("source geometry " + g->name);
+            _source.geometry = makeGeometry(*g, rd);
+            if (src.item("velocityDistribution") && rd.quantity(src, "velocityMagnitude", "velocity", "0") && !_oligo)
+                unsupported("a source with a velocity field");
+        }
+        else
+            unsupported("source " + src.name);
+        if (const XmlElement* sed = src.item("sed"))
+        {
+            if (sed->name != "BlackBodySED") unsupported("SED " + sed->name);
+            _source.temperature = rd.quantity(*sed, "temperature", "temperature", "5000 K");
+        }
+        if (const XmlElement* norm = src.item("normalization"))
+        {
+            if (norm->name != "IntegratedLuminosityNormalization") unsupported("luminosity normalization " + norm->name);
+            _source.normRange = norm->attr("wavelengthRange", "Source");
+            _source.normMinWavelength = rd.quantity(*norm, "minWavelength", "wavelength", "0.09 micron");
+            _source.normMaxWavelength = rd.quantity(*norm, "maxWavelength", "wavelength", "100 micron");
+            _source.integratedLuminosity = rd.quantity(*norm, "integratedLuminosity", "bolluminosity");
+        }
+        else
+            throw std::runtime_error("ski: source lacks a luminosity normalization");
+        if (const XmlElement* bd = src.item("wavelengthBiasDistribution"))
+        {
+            _source.biasDistType = bd->name;
+            if (bd->name == "LogWavelengthDistribution" || bd->name == "LinWavelengthDistribution")
+            {
+                _source.biasMin = rd.quantity(*bd, "minWavelength", "wavelength", "1 pm");
+                _source.biasMax = rd.quantity(*bd, "maxWavelength", "wavelength", "1 m");
+            }
+            else if (bd->name != "DefaultWavelengthDistribution")
+                unsupported("wavelength bias distribution " + bd->name);
+        }
+
+        // ---- medium system
+        const XmlElement* ms = sim.item("mediumSystem");
+        if (!ms) unsupported("a simulation without a medium system");
+        _options.force_scattering = 1;
+        _options.min_weight_reduction = 1e4;
+        _options.min_scatt_events = 0;
+        _options.path_length_bias = 0.5;
+        if (const XmlElement* po = ms->item("photonPacketOptions"))
+        {
+            if (rd.boolean(*po, "explicitAbsorption", false)) unsupported("explicitAbsorption");
+            _options.force_scattering = rd.boolean(*po, "forceScattering", true);
+            _options.min_weight_reduction = rd.number(*po, "minWeightReduction", "1e4");
+            _options.min_scatt_events = rd.integer(*po, "minScattEvents", 0);
+            _options.path_length_bias = rd.number(*po, "pathLengthBias", _options.force_scattering ? "0.5" : "0");
+        }
+        if (const XmlElement* rf = ms->item("radiationFieldOptions"))
+            if (rd.boolean(*rf, "storeRadiationField", false)) unsupported("storeRadiationField");
+        if (const XmlElement* so = ms->item("samplingOptions")) _numDensitySamples = rd.integer(*so, "numDensitySamples", 100);
+        auto media = ms->items("media");
+        if (media.size() != 1) unsupported("a medium system with " + std::to_string(media.size()) + " media");
+        const XmlElement& med = *media[0];
+        if (med.name != "GeometricMedium") unsupported("medium " + med.name);
+        if (med.item("velocityDistribution") && rd.quantity(med, "velocityMagnitude", "velocity", "0") && !_oligo)
+            unsupported("a medium with a velocity field");
+        if (med.item("magneticFieldDistribution") && rd.quantity(med, "magneticFieldStrength", "magneticfield", "0"))
+            unsupported("a medium with a magnetic field");
+        _medium = std::make_unique<GeometricMedium>();
+        const XmlElement* mg = med.item("geometry");
+        if (!mg) throw std::runtime_error("ski: GeometricMedium lacks a geometry");
+        _medium->geometry = makeGeometry(*mg, rd);
+        const XmlElement* mm = med.item("materialMix");
+        if (!mm) throw std::runtime_error("ski: GeometricMedium lacks a material mix");
+        if (mm->name != "MeanListDustMix") unsupported("material mix " + mm->name);
+        _medium->mix = std::make_unique<DustMix>();
+        _medium->mix->typeName = mm->name;
+        _medium->mix->inLambda = rd.list(*mm, "wavelengths", "wavelength", "");
+        _medium->mix->inKappaExt = rd.list(*mm, "extinctionCoefficients", "masscoefficient", "");
+        _medium->mix->inAlbedo = rd.list(*mm, "albedos", "", "");
+        _medium->mix->inAsymmpar = rd.list(*mm, "asymmetryParameters", "", "");
+        const XmlElement* mn = med.item("normalization");
+        if (!mn) throw std::runtime_error("ski: GeometricMedium lacks a normalization");
+        _medium->normType = mn->name;
+        if (mn->name == "OpticalDepthMaterialNormalization")
+        {
+            std::string axis = mn->attr("axis", "Z");
+            _medium->normAxis = axis.empty() ? 'Z' : axis[0];
+            _medium->normWavelength = rd.quantity(*mn, "wavelength", "wavelength");
+            _medium->normOpticalDepth = rd.number(*mn, "opticalDepth");
+        }
+        else if (mn->name == "MassMaterialNormalization")
+            _medium->normMass = rd.quantity(*mn, "mass", "mass");
+        else if (mn->name == "NumberMaterialNormalization")
+            _medium->normNumber = rd.number(*mn, "number");
+        else
+            unsupported("material normalization " + mn->name);
+
+        const XmlElement* ge = ms->item("grid");
+        if (!ge) throw std::runtime_error("ski: MediumSystem lacks a spatial grid");
+        Box extent(rd.quantity(*ge, "minX", "length"), rd.quantity(*ge, "minY", "length"), rd.quantity(*ge, "minZ", "length"),
+                   rd.quantity(*ge, "maxX", "length"), rd.quantity(*ge, "maxY", "length"), rd.quantity(*ge, "maxZ", "length"));
+        if (ge->name == "CartesianSpatialGrid")
+        {
+            auto grid = std::make_unique<CartesianSpatialGrid>();
+            grid->extent = extent;
+            auto bins = [&](const char* prop) {
+                const XmlElement* mesh = ge->item(prop);
+                if (!mesh) return 100;  // Mesh default numBins
+                if (mesh->name != "LinMesh") unsupported("mesh " + mesh->name);
+                return rd.integer(*mesh, "numBins", 100);
+            };
+            grid->nx = bins("meshX");
+            grid->ny = bins("meshY");
+            grid->nz = bins("meshZ");
+            _grid = std::move(grid);
+        }
+        else if (ge->name == "PolicyTreeSpatialGrid")
+        {
+            if (ge->attr("treeType", "OctTree") != "OctTree") unsupported("treeType " + ge->attr("treeType"));
+            auto grid = std::make_unique<OctreeSpatialGrid>();
+            grid->extent = extent;
+            if (const XmlElement* pol = ge->item("policy"))
+            {
+                if (pol->name != "DensityTreePolicy") unsupported("tree policy " + pol->name);
+                grid->minLevel = rd.integer(*pol, "minLevel", 3);
+                grid->maxLevel = rd.integer(*pol, "maxLevel", 7);
+                grid->maxDustFraction = rd.number(*pol, "maxDustFraction", "1e-6");
+                grid->maxDustOpticalDepth = rd.number(*pol, "maxDustOpticalDepth", "0");
+                grid->policyWavelength = rd.quantity(*pol, "wavelength", "wavelength", "0.55 micron");
+                grid->maxDustDensityDispersion = rd.number(*pol, "maxDustDensityDispersion", "0");
+            }
+            _grid = std::move(grid);
+        }
+        else
+            unsupported("spatial grid " + ge->name);
+
+        // ---- instrument system
+        const XmlElement* is = sim.item("instrumentSystem");
+        if (!is) throw std::runtime_error("ski: missing instrumentSystem");
+        if (const XmlElement* dg = is->item("defaultWavelengthGrid")) _defaultGrid = makeWavelengthGrid(*dg, rd);
+        for (const XmlElement* ie : is->items("instruments"))
+        {
+            InstrumentModel ins;
+            ins.type = ie->name;
+            if (ie->name != "FrameInstrument" && ie->name != "FullInstrument") unsupported("instrument " + ie->name);
+            ins.name = ie->attr("instrumentName");
+            ins.distance = rd.quantity(*ie, "distance", "distance");
+            ins.inclination = rd.quantity(*ie, "inclination", "posangle", "0 deg");
+            ins.azimuth = rd.quantity(*ie, "azimuth", "posangle", "0 deg");
+            ins.roll = rd.quantity(*ie, "roll", "posangle", "0 deg");
+            ins.fieldOfViewX = rd.quantity(*ie, "fieldOfViewX", "length");
+            ins.fieldOfViewY = rd.quantity(*ie, "fieldOfViewY", "length");
+            ins.centerX = rd.quantity(*ie, "centerX", "length", "0");
+            ins.centerY = rd.quantity(*ie, "centerY", "length", "0");
+            ins.numPixelsX = rd.integer(*ie, "numPixelsX", 250);
+            ins.numPixelsY = rd.integer(*ie, "numPixelsY", 250);
+            ins.recordComponents = rd.boolean(*ie, "recordComponents", false);
+            ins.numScatteringLevels = rd.integer(*ie, "numScatteringLevels", 0);
+            ins.recordPolarization = rd.boolean(*ie, "recordPolarization", false);
+            ins.recordStatistics = rd.boolean(*ie, "recordStatistics", false);
+            if (ins.recordPolarization) unsupported("recordPolarization");
+            if (ins.distance <= 0.) unsupported("an instrument at zero distance (model redshift)");
+            if (const XmlElement* wg = ie->item("wavelengthGrid")) ins.ownGrid = makeWavelengthGrid(*wg, rd);
+            _instruments.push_back(std::move(ins));
+        }
+        if (_instruments.empty()) unsupported("a simulation without instruments");
+    }
+
+    // ================================================================ setup
+
+    void Simulation::setup()
+    {
+        _random.setSeed(_seed);
+
+        // ---- Configuration: wavelength regime (Configuration.cpp:58-73)
+        double sourceMin, sourceMax;
+        if (_oligo)
+        {
+            _oligoGrid = std::make_unique<WavelengthGrid>();
+            _oligoGrid->setWavelengthBins(_oligoWavelengths, 1e-3, true);  // OligoWavelengthGrid.cpp:20-26
+            sourceMin = _oligoGrid->rangeMin();
+            sourceMax = _oligoGrid->rangeMax();
+        }
+        else
+        {
+            sourceMin = _ssMinWavelength;
+            sourceMax = _ssMaxWavelength;
+        }
+        const WavelengthGrid* defaultGrid = _oligo ? _oligoGrid.get() : _defaultGrid.get();
+
+        // instruments: grid in effect (Configuration::wavelengthGrid, Configuration.cpp:666-671) and observer sharing
+        // (DistantInstrument::determineSameObserverAsPreceding, DistantInstrument.cpp:55-63)
+        for (size_t i = 0; i < _instruments.size(); ++i)
+        {
+            InstrumentModel& ins = _instruments[i];
+            ins.grid = (ins.ownGrid && !_oligo) ? ins.ownGrid.get() : defaultGrid;
+            if (!ins.grid) throw std::runtime_error("Cannot find a wavelength grid for instrument or probe");
+            if (i > 0)
+            {
+                const InstrumentModel& o = _instruments[i - 1];
+                ins.sameObserverAsPreceding = ins.distance == o.distance && ins.inclination == o.inclination
+                                              && ins.azimuth == o.azimuth && ins.roll == o.roll;
+            }
+        }
+
+        // ---- Configuration::simulationWavelengthRange / simulationWavelengths (Configuration.cpp:566-661)
+        double rangeMin = sourceMin, rangeMax = sourceMax;
+        auto extend = [&](double lo, double hi) {
+            if (lo < rangeMin) rangeMin = lo;
+            if (hi > rangeMax) rangeMax = hi;
+        };
+        std::set<double> simWavelengths;
+        auto addGrid = [&](const WavelengthGrid* g) {
+            extend(g->rangeMin(), g->rangeMax());
+            for (double w : g->lambdav) simWavelengths.insert(w);
+        };
+        if (defaultGrid) addGrid(defaultGrid);
+        for (auto& ins : _instruments)
+            if (ins.ownGrid) addGrid(ins.ownGrid.get());
+        // MaterialWavelengthRangeInterface items: the normalisation wavelength and the tree policy wavelength
+        if (_medium->normType == "OpticalDepthMaterialNormalization" && _medium->normWavelength > 0)
+        {
+            extend(_medium->normWavelength, _medium->normWavelength);
+            simWavelengths.insert(_medium->normWavelength);
+        }
+        if (auto tree = dynamic_cast<OctreeSpatialGrid*>(_grid.get()))
+            if (tree->maxDustOpticalDepth > 0 && tree->policyWavelength > 0)
+            {
+                extend(tree->policyWavelength, tree->policyWavelength);
+                simWavelengths.insert(tree->policyWavelength);
+            }
+        rangeMin /= (1. + 1. / 100.);  // Range::extendWithRedshift
+        rangeMax *= (1. + 1. / 100.);
+
+        // ---- dust mix, medium normalisation
+        _medium->mix->setup(rangeMin, rangeMax, std::vector<double>(simWavelengths.begin(), simWavelengths.end()));
+        _medium->setup();
+
+        // ---- spatial grid (tree construction draws from the random stream) then cell densities
+        if (auto cart = dynamic_cast<CartesianSpatialGrid*>(_grid.get()))
+            cart->setup();
+        else if (auto tree = dynamic_cast<OctreeSpatialGrid*>(_grid.get()))
+        {
+            if (!_topology.empty())
+                tree->setupFromTopology(_topology);
+            else
+                tree->setup(*_medium, _numDensitySamples, _random);
+        }
+
+        // MediumSystem::setupSelfAfter density sampling (MediumSystem.cpp:80-106,308-321)
+        int numCells = _grid->numCells();
+        _density.assign(numCells, 0.);
+        for (int m = 0; m != numCells; ++m)
+        {
+            Box box = _grid->cellBox(m);
+            if (_numDensitySamples == 1)
+                _density[m] = _medium->numberDensity(box.center());
+            else
+            {
+                double sum = 0.;
+                std::vector<double> samples(_numDensitySamples);
+                for (int n = 0; n != _numDensitySamples; ++n) samples[n] = _medium->numberDensity(_random.position(box));
+                for (int n = 0; n != _numDensitySamples; ++n) sum += samples[n];
+                _density[m] = sum / _numDensitySamples;
+            }
+        }
+
+        // ---- source: luminosity and wavelength sampling tables
+        // BlackBodySED (BlackBodySED.cpp:12-39) over the normalisation range = source range
+        const double h = constants::h, c = constants::c, k = constants::k;
+        double f1 = h * c / (k * _source.temperature);
+        double f2 = 2.0 * h * c * c;
+        auto planck = [&](double lambda) { return f2 / pow(lambda, 5) / (exp(f1 / lambda) - 1.0); };
+        auto planckCdf = [&](Array& lambdav, Array& pv, Array& Pv, double lo, double hi) {
+            size_t n = std::max(static_cast<size_t>(100), static_cast<size_t>(1000. * log10(hi / lo)));
+            nr::logGrid(lambdav, lo, hi, static_cast<int>(n));
+            pv.resize(n + 1);
+            for (size_t i = 0; i <= n; ++i) pv[i] = planck(lambdav[i]);
+            return nr::cdf2(true, lambdav, pv, Pv);
+        };
+        double Ltot = planckCdf(_sedLambda, _sedp, _sedP, sourceMin, sourceMax);
+        auto specificLuminosity = [&](double lambda) { return planck(lambda) / Ltot; };
+
+        // IntegratedLuminosityNormalization::luminosityForSED (IntegratedLuminosityNormalization.cpp:12-31)
+        if (_source.normRange == "Source")
+            _sourceLuminosity = _source.integratedLuminosity;
+        else
+        {
+            double lo = _source.normRange == "Custom" ? _source.normMinWavelength : 1e-10;
+            double hi = _source.normRange == "Custom" ? _source.normMaxWavelength : 1;
+            if (lo >= hi) throw std::runtime_error("the normalization wavelength range is empty");
+            Array a, b, cc;
+            double L = planckCdf(a, b, cc, lo, hi) / Ltot;
+            if (L <= 0) throw std::runtime_error("the normalization luminosity is zero");
+            _sourceLuminosity = _source.integratedLuminosity / L;
+        }
+
+        // SourceSystem::setupSelfAfter / prepareForLaunch / launch for one source (SourceSystem.cpp:14-40,75-112)
+        double Lsys = _sourceLuminosity;  // _Lv.sum()
+        double Lv0 = _sourceLuminosity / Lsys;
+        double wv0 = _source.sourceWeight;
+        double wLv0 = wv0 * Lv0;
+        double xi = _sourceBias;
+        double Wv0 = (1 - xi) * wLv0 / wLv0 + xi * wv0 / wv0;
+        double Lpp = Lsys / _numPackets;
+        double launchWeight = Lv0 / Wv0;
+
+        buildScene();
+        _scene.source.packet_luminosity = _numPackets ? Lpp * launchWeight : 0.;
+
+        if (_oligo)
+        {
+            // NormalizedSource::launch with xi = 1 and OligoWavelengthDistribution (NormalizedSource.cpp:26-29,73-110;
+            // OligoWavelengthDistribution.cpp:13-41)
+            const Array& lam = _oligoGrid->lambdav;
+            double probability = 1. / _oligoGrid->numBins() / _oligoGrid->effectiveWidth(0);
+            const double xil = 1.;
+            _oligoWeight.assign(lam.size(), 0.);
+            for (size_t i = 0; i < lam.size(); ++i)
+            {
+                double s = specificLuminosity(lam[i]);
+                if (!s)
+                    _oligoWeight[i] = 0.;
+                else
+                {
+                    double b = probability;
+                    _oligoWeight[i] = s / ((1 - xil) * s + xil * b);
+                }
+            }
+            _scene.source.lambda_mode = PMC_LAMBDA_OLIGO;
+            _scene.source.num_oligo = static_cast<int32_t>(lam.size());
+            _scene.source.oligo_lambda = lam.data();
+            _scene.source.oligo_weight = _oligoWeight.data();
+        }
+        else
+        {
+            _scene.source.lambda_mode = PMC_LAMBDA_TABULATED;
+            _scene.source.lambda_bias = _source.wavelengthBias;
+            _scene.source.num_sed = static_cast<int32_t>(_sedLambda.size());
+            _scene.source.sed_lambda = _sedLambda.data();
+            _scene.source.sed_p = _sedp.data();
+            _scene.source.sed_P = _sedP.data();
+            // bias distribution range: Default = source range; Log/Lin = configured range intersected with source range
+            double lo = sourceMin, hi = sourceMax;
+            if (_source.biasDistType != "DefaultWavelengthDistribution")
+            {
+                lo = std::max(lo, _source.biasMin);
+                hi = std::min(hi, _source.biasMax);
+                if (!(lo < hi)) throw std::runtime_error("Wavelength distribution range does not overlap source wavelength range");
+            }
+            _scene.source.bias_kind = _source.biasDistType == "LinWavelengthDistribution" ? PMC_BIAS_LIN : PMC_BIAS_LOG;
+            _scene.source.bias_min = lo;
+            _scene.source.bias_max = hi;
+        }
+    }
+
+    // ================================================================ scene flattening
+
+    void Simulation::buildScene()
+    {
+        std::memset(&_scene, 0, sizeof(_scene));
+        _scene.abi_version = PMC_ABI_VERSION;
+
+        pmc_grid& g = _scene.grid;
+        g.xmin = _grid->extent.xmin;
+        g.ymin = _grid->extent.ymin;
+        g.zmin = _grid->extent.zmin;
+        g.xmax = _grid->extent.xmax;
+        g.ymax = _grid->extent.ymax;
+        g.zmax = _grid->extent.zmax;
+        g.eps = 1e-12 * _grid->extent.diagonal();
+        g.num_cells = _grid->numCells();
+        _grid->fill(g);
+
+        pmc_medium& m = _scene.medium;
+        m.number_density = _density.data();
+        m.num_lambda = static_cast<int32_t>(_medium->mix->lambdaBorder.size());
+        m.lambda_border = _medium->mix->lambdaBorder.data();
+        m.sigma_ext = _medium->mix->sigmaExt.data();
+        m.sigma_sca = _medium->mix->sigmaSca.data();
+        m.asymmpar = _medium->mix->asymmpar.data();
+
+        _scene.options = _options;
+
+        pmc_source& s = _scene.source;
+        if (_source.type == "PointSource")
+        {
+            s.kind = PMC_SOURCE_POINT;
+            s.position[0] = _source.position.x;
+            s.position[1] = _source.position.y;
+            s.position[2] = _source.position.z;
+        }
+        else if (auto sersic = dynamic_cast<SersicGeometry*>(_source.geometry.get()))
+        {
+            s.kind = PMC_SOURCE_SERSIC;
+            s.reff = sersic->reff();
+            s.sersic_n = static_cast<int32_t>(sersic->function().sv().size());
+            s.sersic_s = sersic->function().sv().data();
+            s.sersic_M = sersic->function().Mv().data();
+        }
+        else if (auto ubox = dynamic_cast<UniformBoxGeometry*>(_source.geometry.get()))
+        {
+            s.kind = PMC_SOURCE_UNIFORM_BOX;
+            const Box& b = ubox->box();
+            double v[6] = {b.xmin, b.ymin, b.zmin, b.xmax, b.ymax, b.zmax};
+            std::memcpy(s.box, v, sizeof(v));
+        }
+
+        // instruments (DistantInstrument.cpp:13-51, FrameInstrument.cpp:12-33, FullInstrument.cpp:11-17)
+        _pmcInstruments.assign(_instruments.size(), pmc_instrument{});
+        for (size_t i = 0; i < _instruments.size(); ++i)
+        {
+            const InstrumentModel& ins = _instruments[i];
+            pmc_instrument& p = _pmcInstruments[i];
+            p.costheta = cos(ins.inclination);
+            p.sintheta = sin(ins.inclination);
+            p.cosphi = cos(ins.azimuth);
+            p.sinphi = sin(ins.azimuth);
+            p.cosomega = cos(ins.roll);
+            p.sinomega = sin(ins.roll);
+            // Direction(theta, phi) (Direction.cpp:11-38)
+            const double eps = 1e-8;
+            double theta = ins.inclination, phi = ins.azimuth;
+            if (theta < -eps || theta > M_PI + eps) throw std::runtime_error("Theta should be between 0 and pi.");
+            if (theta <= eps)
+                p.kobs[0] = 0, p.kobs[1] = 0, p.kobs[2] = 1;
+            else if (theta >= M_PI - eps)
+                p.kobs[0] = 0, p.kobs[1] = 0, p.kobs[2] = -1;
+            else
+            {
+                double sintheta = sin(theta);
+                p.kobs[0] = sintheta * cos(phi);
+                p.kobs[1] = sintheta * sin(phi);
+                p.kobs[2] = cos(theta);
+            }
+            p.nxp = ins.numPixelsX;
+            p.nyp = ins.numPixelsY;
+            p.xpmin = ins.centerX - 0.5 * ins.fieldOfViewX;
+            p.xpsiz = ins.fieldOfViewX / ins.numPixelsX;
+            p.ypmin = ins.centerY - 0.5 * ins.fieldOfViewY;
+            p.ypsiz = ins.fieldOfViewY / ins.numPixelsY;
+            p.same_observer_as_preceding = ins.sameObserverAsPreceding;
+            p.include_flux_density = ins.type == "FullInstrument";
+            p.include_surface_brightness = 1;
+            p.record_components = ins.recordComponents;  // a medium is always present on this path
+            p.num_scattering_levels = ins.recordComponents ? ins.numScatteringLevels : 0;
+            p.record_statistics = ins.recordStatistics;
+            p.redshift = 0.;
+            p.num_lambda = ins.grid->numBins();
+            p.num_border = static_cast<int32_t>(ins.grid->borderv.size());
+            p.border = ins.grid->borderv.data();
+            p.ellv = ins.grid->ellv.data();
+        }
+        _scene.num_instruments = static_cast<int32_t>(_pmcInstruments.size());
+        _scene.instruments = _pmcInstruments.data();
+
+        _layouts.resize(_instruments.size());
+        for (size_t i = 0; i < _instruments.size(); ++i) _frameSize = pmc_layout_compute(&_scene, static_cast<int32_t>(i), &_layouts[i]);
+    }
+
+    std::string Simulation::summary() const
+    {
+        std::ostringstream s;
+        s << "simulation " << _prefix << ": " << (_oligo ? "oligochromatic" : "panchromatic") << ", " << _numPackets
+          << " packets, seed " << _seed << "\n";
+        s << "  grid: " << (_scene.grid.kind == PMC_GRID_CARTESIAN ? "Cartesian" : "octree") << " with " << _scene.grid.num_cells
+          << " cells";
+        if (_scene.grid.kind == PMC_GRID_OCTREE) s << " (" << _scene.grid.num_nodes << " nodes)";
+        s << "\n  dust table: " << _scene.medium.num_lambda << " wavelengths; setup draws: " << _random.draws() << "\n";
+        s << "  instruments: " << _instruments.size() << "; frame buffer: " << _frameSize << " doubles\n";
+        return s.str();
+    }
+}
