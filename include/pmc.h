@@ -192,6 +192,8 @@ typedef struct pmc_counter_values
     uint64_t detector_updates; /* U: f64 atomic adds into flux/statistics arrays */
     uint64_t scatterings;      /* scattering events simulated */
     uint64_t stat_overflows;   /* histories whose per-history contribution list overflowed (should be 0) */
+    uint64_t rewalk_visits;    /* engine only: cell visits of the second pass over a forced-scattering path (the
+                                  reference stores the path instead); NOT part of V */
 } pmc_counter_values;
 
 typedef struct pmc_ctx pmc_ctx;

@@ -1,0 +1,133 @@
+"""ctypes binding of the HIP engine (libpmc.so, include/pmc.h).
+
+The engine replaces the parallel section of ``MonteCarloSimulation::runPrimaryEmission``
+(SKIRT/core/MonteCarloSimulation.cpp:126-129: ``parallel->call(Npp, performLifeCycle)`` followed by
+``instrumentSystem()->flush()``).  There is NO CPU fallback: importing works anywhere (so that the build can be
+checked on a machine without a GPU) but creating an ``Engine`` without a HIP device raises ``RuntimeError``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .host import CounterValues, FrameLayout
+
+_LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+
+# every symbol include/pmc.h declares
+SYMBOLS = ["pmc_abi_version", "pmc_last_error", "pmc_frame_layout_of", "pmc_create", "pmc_destroy", "pmc_bind_frames",
+           "pmc_clear_frames", "pmc_run_primary", "pmc_sync", "pmc_download", "pmc_frames_device", "pmc_frames_size",
+           "pmc_last_kernel_ms", "pmc_counters", "pmc_reset_counters", "pmc_trace_ray", "pmc_set_launch"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_LIBDIR, "libpmc.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: the HIP engine has not been built (run `make` or "
+                               "__graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(path)
+        L.pmc_abi_version.restype = C.c_int
+        L.pmc_last_error.restype = C.c_char_p
+        L.pmc_frame_layout_of.restype = C.c_int64
+        L.pmc_frame_layout_of.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FrameLayout)]
+        L.pmc_create.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+        L.pmc_destroy.argtypes = [C.c_void_p]
+        L.pmc_bind_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.pmc_clear_frames.argtypes = [C.c_void_p]
+        L.pmc_run_primary.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.pmc_sync.argtypes = [C.c_void_p]
+        L.pmc_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.pmc_frames_device.restype = C.c_void_p
+        L.pmc_frames_device.argtypes = [C.c_void_p]
+        L.pmc_frames_size.restype = C.c_int64
+        L.pmc_frames_size.argtypes = [C.c_void_p]
+        L.pmc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.pmc_counters.argtypes = [C.c_void_p, C.POINTER(CounterValues)]
+        L.pmc_reset_counters.argtypes = [C.c_void_p]
+        L.pmc_trace_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.pmc_set_launch.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(f"pmc error {rc}: {lib().pmc_last_error().decode()}")
+
+
+class Engine:
+    """One engine context on one MI355X: device copies of a scene plus the detector arrays."""
+
+    def __init__(self, scene_ptr, device=0):
+        """scene_ptr: address of a pmc_scene (e.g. ``skirt9_amd.host.Simulation.scene``)"""
+        self._h = C.c_void_p()
+        _check(lib().pmc_create(scene_ptr, device, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pmc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def frame_size(self):
+        return int(lib().pmc_frames_size(self._h))
+
+    @property
+    def frames_device_ptr(self):
+        return int(lib().pmc_frames_device(self._h))
+
+    def bind_frames(self, device_ptr, num_doubles):
+        """accumulate into caller-owned device memory (e.g. ``tensor.data_ptr()`` of a zeroed float64 torch tensor)"""
+        _check(lib().pmc_bind_frames(self._h, C.c_void_p(device_ptr), num_doubles))
+
+    def set_launch(self, block=0, grid=0):
+        _check(lib().pmc_set_launch(self._h, block, grid))
+
+    def clear(self):
+        _check(lib().pmc_clear_frames(self._h))
+
+    def run_primary(self, first, count, seed):
+        """asynchronous launch of histories [first, first+count); accumulates into the frames"""
+        _check(lib().pmc_run_primary(self._h, first, count, seed))
+
+    def sync(self):
+        _check(lib().pmc_sync(self._h))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        _check(lib().pmc_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def download(self):
+        out = np.empty(self.frame_size, dtype=np.float64)
+        _check(lib().pmc_download(self._h, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def counters(self):
+        c = CounterValues()
+        _check(lib().pmc_counters(self._h, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        _check(lib().pmc_reset_counters(self._h))
+
+    def trace_ray(self, r, k, cap=4096):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        k = np.ascontiguousarray(k, dtype=np.float64)
+        m = np.zeros(cap, dtype=np.int32)
+        ds = np.zeros(cap, dtype=np.float64)
+        n = C.c_int32(0)
+        _check(lib().pmc_trace_ray(self._h, r.ctypes.data_as(C.c_void_p), k.ctypes.data_as(C.c_void_p),
+                                   m.ctypes.data_as(C.c_void_p), ds.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        return m[:n.value].copy(), ds[:n.value].copy()

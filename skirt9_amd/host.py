@@ -22,7 +22,8 @@ class FrameLayout(C.Structure):
 class CounterValues(C.Structure):
     """pmc_counter_values (include/pmc.h)"""
     _fields_ = [("histories", C.c_uint64), ("paths", C.c_uint64), ("cell_visits", C.c_uint64),
-                ("detector_updates", C.c_uint64), ("scatterings", C.c_uint64), ("stat_overflows", C.c_uint64)]
+                ("detector_updates", C.c_uint64), ("scatterings", C.c_uint64), ("stat_overflows", C.c_uint64),
+                ("rewalk_visits", C.c_uint64)]
 
     def as_dict(self):
         return {name: int(getattr(self, name)) for name, _ in self._fields_}
