@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- photon packets/s of the MI355X primary-emission engine on BASELINE.json's configs[1]:
+Sersic source, ~10^6-cell octree dust grid (953 688 cells, tests/ski/cfg2.ski), monochromatic, peel-off to one
+FullInstrument 512^2 with component + statistics recording, 10^8 packets per step and GPU.
+
+  python bench.py --gpus N --steps K --warmup W [--packets P]
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one segment: every rank runs P histories of its own index range through the HIP engine and the
+detector frames of all ranks are summed onto rank 0 with ONE RCCL reduce (the counterpart of
+ProcessManager::sumToRoot at FluxRecorder.cpp:487-493).  Inputs (grid, densities, tables) are resident in HBM
+before the timed region.  Prints one JSON line (rank 0).
+
+roofline: HBM-bound walk.  achieved = algorithmic bytes per launch (V*20 + U*8 with V = cell visits and U = detector
+updates, both COUNTED by the kernel) / mean kernel time measured with HIP events on the engine's stream.
+cpu_baseline: the unmodified reference (oracle/_ref, built by oracle/Makefile.ref) run on the host cores of this box
+on a bounded number of packets of the same ski file; falls back to the scalar CPU oracle if the binary is absent.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SKI = os.path.join(ROOT, "tests", "ski", "cfg2.ski")
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(packets_per_core=15000):
+    """photon packets/s of the CPU path on this box's host cores, on a bounded sample (about 10-30 s)"""
+    cores = min(os.cpu_count() or 1, 24)  # the reference caps a process at 24 threads (ParallelFactory.cpp:43-50)
+    ref = os.path.join(ROOT, "oracle", "_ref", "release", "SKIRT", "main", "skirt_ref")
+    if os.path.exists(ref):
+        n = packets_per_core * cores
+        with tempfile.TemporaryDirectory() as tmp:
+            text = open(SKI).read().replace('numPackets="1e5"', f'numPackets="{n}"')
+            ski = os.path.join(tmp, "cfg2cpu.ski")
+            open(ski, "w").write(text)
+            try:
+                subprocess.run([ref, "run", ski, "-t", str(cores), "-o", tmp], check=True, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=900, cwd=tmp)
+                log = open(os.path.join(tmp, "cfg2cpu_log.txt")).read()
+                m = re.search(r"Finished primary emission in ([0-9.]+) s", log)
+                if m and float(m.group(1)) > 0:
+                    return {"value": n / float(m.group(1)), "unit": "photon packets/s", "cores": cores, "kind": "reference",
+                            "sample": f"unmodified SKIRT 9 (oracle/_ref), cfg2.ski scene, {n} packets, -t {cores}; "
+                                      f"'Finished primary emission' {m.group(1)} s"}
+            except Exception as exc:  # noqa: BLE001 - the baseline is informational
+                sys.stderr.write(f"[bench] reference baseline failed: {exc}\n")
+    # scalar port on one core
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from skirt9_amd.host import Simulation
+    sim = Simulation(SKI, num_packets=20000).setup()
+    t0 = time.time()
+    O.run_primary(sim, 0, 20000, O.RNG_PHILOX, seed=1)
+    dt = time.time() - t0
+    return {"value": 20000 / dt, "unit": "photon packets/s", "cores": 1, "kind": "port",
+            "sample": "oracle/life_cycle.cpp, cfg2.ski scene, 20000 packets, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--packets", type=float, default=1e8, help="photon packets per step and GPU")
+    ap.add_argument("--ski", default=SKI)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from skirt9_amd.engine import Engine
+    from skirt9_amd.host import Simulation
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    P = int(args.packets)
+    total_per_step = P * world
+    # every rank sets up the same scene (replica of grid, densities, tables); numPackets = packets of one step over
+    # all ranks, so that the per-packet luminosity is that of the whole segment
+    sim = Simulation(args.ski, num_packets=total_per_step).setup()
+    eng = Engine(sim.scene, local_rank)
+    frames = torch.zeros(sim.frame_size, dtype=torch.float64, device=f"cuda:{local_rank}")
+    eng.bind_frames(frames.data_ptr(), frames.numel())
+    seed = sim.seed
+
+    def step(index):
+        # static split of the segment's history range over the ranks; a fresh range per step
+        first = (index * world + rank) * P
+        eng.run_primary(first, P, seed)
+        eng.sync()
+        if world > 1:
+            dist.reduce(frames, dst=0, op=dist.ReduceOp.SUM)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(w)
+    frames.zero_()
+    eng.reset_counters()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for s in range(args.steps):
+        step(args.warmup + s)
+        kernel_ms.append(eng.last_kernel_ms())
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    counters = eng.counters()
+    if rank == 0:
+        launches = max(1, args.steps)
+        V = counters["cell_visits"] / launches
+        U = counters["detector_updates"] / launches
+        bytes_per_launch = 20.0 * V + 8.0 * U
+        mean_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
+        value = total_per_step * args.steps / elapsed
+        out = {
+            "metric": "photon packets/s (whole node), 10^6-cell octree",
+            "value": value,
+            "unit": "photon packets/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: Sersic source, 953688-cell PolicyTreeSpatialGrid octree "
+                                   "(exp-disk dust, tau_z=1), 0.55 micron, forced scattering, peel-off to one "
+                                   "FullInstrument 512^2 (components + statistics), tests/ski/cfg2.ski",
+                       "packets_per_step_per_gpu": P, "cells": 953688, "parallelism": f"history-range x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "primaryEmissionKernel<octree>", "kernel_ms": mean_ms,
+                         "cell_visits_per_packet": V / P, "detector_updates_per_packet": U / P,
+                         "rewalk_visits_per_packet": counters["rewalk_visits"] / launches / P,
+                         "algorithmic_bytes_per_packet": bytes_per_launch / P},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

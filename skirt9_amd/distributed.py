@@ -1,0 +1,26 @@
+"""Multi-GPU sharding of a primary-emission segment: one process per GPU, torch.distributed (backend "nccl" = RCCL on
+ROCm; "gloo" in the CPU tests).
+
+Photon histories are independent (performLifeCycle touches only thread-local state and atomically-added detector
+arrays), so a segment of Npp histories is split statically by index -- rank g of G takes
+[floor(g*Npp/G), floor((g+1)*Npp/G)) -- replacing the reference's chunk server (MultiHybridParallel.cpp:26-104).
+Every rank holds a full replica of grid, densities and tables.  The ONE exchange step is the sum of the detector
+arrays onto rank 0 at the end of the segment, the counterpart of ProcessManager::sumToRoot
+(FluxRecorder.cpp:487-493, ProcessManager.cpp:223-255).  The statistics arrays (sum of w^k per history) are additive
+too because a history lives on exactly one rank.
+"""
+
+
+def history_range(num_packets, rank, world):
+    """[first, first+count) of this rank for a segment of num_packets histories"""
+    first = (rank * num_packets) // world
+    last = ((rank + 1) * num_packets) // world
+    return first, last - first
+
+
+def reduce_frames(frames, dst=0):
+    """sum the detector-array tensor of every rank onto rank dst (in place on dst); no-op for a single process"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(frames, dst=dst, op=dist.ReduceOp.SUM)
+    return frames

@@ -25,7 +25,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(_LIBDIR, "libpmc.so")
+        path = os.environ.get("PMC_LIBRARY") or os.path.join(_LIBDIR, "libpmc.so")  # override: kernel A/B experiments
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: the HIP engine has not been built (run `make` or "
                                "__graft_entry__.build()); there is no CPU fallback")

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Regenerates the golden fixtures in this directory from the UNMODIFIED reference (oracle/_ref, built by
+`make -f oracle/Makefile.ref`).  Runs only where /root/reference exists; the fixtures themselves are data
+(FITS cubes, SED tables, ray segment lists, per-cell densities) and are committed.
+
+  python tests/golden/make_golden.py
+
+Fixtures:
+  cfg1_*       config 1 (tests/ski/cfg1.ski): 10^6 packets, seed 0, one thread -> FITS/SED/statistics files
+  cfg2small_*  reduced config 2 (tests/ski/cfg2small.ski): 2x10^4 packets -> FITS/SED/statistics files
+  *_rays.txt / *_rays_ref.txt   fixed rays and the reference's (m, ds) sequences (C99 hex floats)
+  *_cells.npz  per-cell volume and number density as the reference computed them (bit patterns), and the dust
+               cross sections at 0.55 micron
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref", "release", "SKIRT", "main", "skirt_ref")
+
+
+def rays(scale, n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        r = (rng.random(3) - 0.5) * 2 * scale * (1.3 if i % 4 == 0 else 0.9)
+        k = rng.normal(size=3)
+        k /= np.linalg.norm(k)
+        out.append((r, k))
+    s2 = 1 / np.sqrt(2.0)
+    out += [(np.zeros(3), np.array([1.0, 0, 0])), (np.zeros(3), np.array([0, -1.0, 0])), (np.zeros(3), np.array([0, 0, 1.0])),
+            (np.zeros(3), np.array([s2, s2, 0])), (np.array([scale * 0.25, scale * 0.125, 0.0]), np.array([0, 0, -1.0])),
+            (np.array([-scale * 2, 0.0, 0.0]), np.array([1.0, 0, 0])), (np.array([-scale * 2, 1.0, 1.0]), np.array([-1.0, 0, 0])),
+            (np.array([1e15, 2e15, -3e15]), np.array([0.3, 0.5, 0.81]) / np.linalg.norm([0.3, 0.5, 0.81]))]
+    return out
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
+    for name, scale in (("cfg1", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16)):
+        ski = os.path.join(ROOT, "tests", "ski", name + ".ski")
+        with tempfile.TemporaryDirectory() as tmp:
+            subprocess.check_call([REF, "run", ski, "-t", "1", "-o", tmp], cwd=tmp, stdout=subprocess.DEVNULL)
+            for f in sorted(os.listdir(tmp)):
+                if f.endswith(".fits") or f.endswith(".dat"):
+                    shutil.copy(os.path.join(tmp, f), os.path.join(HERE, f))
+            # rays: directions are written as hex floats so that both sides parse identical doubles
+            rayfile = os.path.join(HERE, name + "_rays.txt")
+            with open(rayfile, "w") as fh:
+                for r, k in rays(scale, 40, 1):
+                    fh.write(" ".join(float(v).hex() for v in list(r) + list(k)) + "\n")
+            subprocess.check_call([REF, "rays", ski, rayfile, os.path.join(HERE, name + "_rays_ref.txt"), "-o", tmp], cwd=tmp,
+                                  stdout=subprocess.DEVNULL)
+            cells = os.path.join(tmp, "cells.txt")
+            subprocess.check_call([REF, "cells", ski, cells, "-w", "0.55e-6", "-o", tmp], cwd=tmp, stdout=subprocess.DEVNULL)
+            vol, dens, mix = [], [], None
+            for line in open(cells):
+                t = line.split()
+                if t[0] == "cells":
+                    continue
+                if t[0] == "mix":
+                    mix = [float.fromhex(v) for v in t[1:]]
+                    continue
+                vol.append(float.fromhex(t[4]))
+                dens.append(float.fromhex(t[5]))
+            np.savez_compressed(os.path.join(HERE, name + "_cells.npz"), volume=np.array(vol), density=np.array(dens),
+                                mix=np.array(mix))
+    print("golden fixtures regenerated")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""The C-ABI library of the HIP engine: it must load on a machine without a GPU, export every symbol that
+include/pmc.h declares, answer the pure host helpers, and FAIL LOUDLY (no CPU fallback) when asked to compute
+without a device."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT, ski
+
+
+@pytest.fixture(scope="module")
+def libpmc():
+    path = os.path.join(ROOT, "skirt9_amd", "lib", "libpmc.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-s", "skirt9_amd/lib/libpmc.so"], cwd=ROOT)  # hipcc cross-compiles gfx950
+    from skirt9_amd import engine
+    return engine.lib()
+
+
+def test_every_declared_symbol_is_exported(libpmc):
+    header = open(os.path.join(ROOT, "include", "pmc.h")).read()
+    declared = sorted(set(re.findall(r"\b(pmc_[a-z_]+)\s*\(", header)))
+    from skirt9_amd import engine
+    assert sorted(engine.SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(libpmc, name), name
+    assert libpmc.pmc_abi_version() == 1
+
+
+def test_host_library_exports(libpmc):
+    header = open(os.path.join(ROOT, "include", "skirt_host.h")).read()
+    from skirt9_amd import host
+    L = host.lib()
+    for name in sorted(set(re.findall(r"\b(skh_[a-z_]+)\s*\(", header))):
+        assert hasattr(L, name), name
+
+
+def test_frame_layout_helper_matches_host(libpmc):
+    from skirt9_amd.host import FrameLayout, Simulation
+    sim = Simulation(ski("cfg1.ski"), num_packets=10).setup()
+    out = FrameLayout()
+    total = libpmc.pmc_frame_layout_of(sim.scene, 0, C.byref(out))
+    assert total == sim.frame_size == 3 * 1 + 3 * 4096 + 5 * 1 + 5 * 4096
+    ref = sim.layout(0)
+    for field, _ in FrameLayout._fields_:
+        assert getattr(out, field) == getattr(ref, field)
+
+
+def test_no_cpu_fallback(libpmc):
+    """without a HIP device pmc_create must return an error and say why; nothing computes on the CPU"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from skirt9_amd.engine import Engine
+    from skirt9_amd.host import Simulation
+    sim = Simulation(ski("cfg1.ski"), num_packets=10).setup()
+    with pytest.raises(RuntimeError) as err:
+        Engine(sim.scene, 0)
+    assert "no hip device" in str(err.value).lower() or "pmc error" in str(err.value).lower()
+
+
+def test_product_does_not_reference_the_oracle():
+    """the oracle is test infrastructure: nothing under skirt9_amd/ or include/ may import, link or open it"""
+    for base in ("skirt9_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "oracle_lib" not in text and "liboracle" not in text and "oracle/" not in text.replace("test oracle", ""), f
+    mk = open(os.path.join(ROOT, "Makefile")).read()
+    rule = mk[mk.index("skirt9_amd/lib/skirt_mi355x:"):mk.index("# ---- test oracle")]
+    assert "oracle" not in rule
