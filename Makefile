@@ -17,7 +17,7 @@ skirt9_amd/lib/libskirthost.so: $(HOST_LIB_SRC) $(HOST_HDR)
 	@mkdir -p skirt9_amd/lib
 	$(CXX) $(CXXFLAGS) -shared $(HOST_LIB_SRC) -o $@
 
-skirt9_amd/lib/libpmc.so: $(wildcard skirt9_amd/csrc/*.hip) $(wildcard skirt9_amd/csrc/*.h) $(wildcard include/*.h)
+skirt9_amd/lib/libpmc.so: $(wildcard skirt9_amd/csrc/*.hip) $(wildcard skirt9_amd/csrc/*.h) $(wildcard skirt9_amd/csrc/*.inc) $(wildcard include/*.h)
 	@mkdir -p skirt9_amd/lib
 	$(HIPCC) $(HIPFLAGS) -shared $(wildcard skirt9_amd/csrc/*.hip) -o $@
 

@@ -32,7 +32,7 @@ SKI = os.path.join(ROOT, "tests", "ski", "cfg2.ski")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(packets_per_core=15000):
+def cpu_baseline(packets_per_core=100000):
     """photon packets/s of the CPU path on this box's host cores, on a bounded sample (about 10-30 s)"""
     cores = min(os.cpu_count() or 1, 24)  # the reference caps a process at 24 threads (ParallelFactory.cpp:43-50)
     ref = os.path.join(ROOT, "oracle", "_ref", "release", "SKIRT", "main", "skirt_ref")
@@ -122,10 +122,11 @@ def main():
     eng.reset_counters()
     fence()
     t0 = time.perf_counter()
-    kernel_ms = []
+    kernel_ms, timings = [], []
     for s in range(args.steps):
         step(args.warmup + s)
-        kernel_ms.append(eng.last_kernel_ms())
+        kernel_ms.append(eng.last_kernel_ms())   # HIP events around every walk-kernel launch of the segment, summed
+        timings.append(eng.last_timing())
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -161,7 +162,10 @@ def main():
                        "packets_per_step_per_gpu": P, "cells": 953688, "parallelism": f"history-range x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "primaryEmissionKernel<octree>", "kernel_ms": mean_ms,
+                         "kernel": "walkKernel<octree> (all launches of one step)", "kernel_ms": mean_ms,
+                         "transition_kernel_ms": sum(t["transition_ms"] for t in timings) / len(timings),
+                         "segment_ms": sum(t["total_ms"] for t in timings) / len(timings),
+                         "generations": sum(t["generations"] for t in timings) / len(timings),
                          "cell_visits_per_packet": V / P, "detector_updates_per_packet": U / P,
                          "rewalk_visits_per_packet": counters["rewalk_visits"] / launches / P,
                          "algorithmic_bytes_per_packet": bytes_per_launch / P},

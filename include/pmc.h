@@ -211,25 +211,31 @@ void pmc_destroy(pmc_ctx* ctx);
    context's own allocation -- e.g. a torch tensor, so that torch.distributed can reduce it over RCCL. */
 int pmc_bind_frames(pmc_ctx* ctx, double* device_ptr, int64_t num_doubles);
 int pmc_clear_frames(pmc_ctx* ctx);
-/* Launch histories [first, first+count) on the context's stream; results are ACCUMULATED into the frames.
-   Asynchronous: returns after the launch; pmc_sync / pmc_download wait.  The RNG stream of a history depends only
-   on (seed, history index), so any partition of [0,Npp) over calls and devices gives the same result up to the
-   summation order of the floating-point atomics. */
+/* Run histories [first, first+count) on the context's stream; results are ACCUMULATED into the frames.  The host
+   thread drives the generations of the two device kernels and returns when the segment is complete (the frames
+   stay on the device; pmc_download copies them).  The RNG stream of a history depends only on (seed, history
+   index), so any partition of [0,Npp) over calls and devices gives the same result up to the summation order of
+   the floating-point atomics. */
 int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed);
 int pmc_sync(pmc_ctx* ctx);
 int pmc_download(pmc_ctx* ctx, double* host_frames, int64_t num_doubles);
 double* pmc_frames_device(pmc_ctx* ctx);
 int64_t pmc_frames_size(pmc_ctx* ctx);
-/* duration in milliseconds of the most recent pmc_run_primary kernel, measured with HIP events on the context's
-   stream (valid after pmc_sync) */
+/* milliseconds spent in the walk kernel (the dominant kernel) during the most recent pmc_run_primary, summed over
+   its launches and measured with HIP events on the context's stream */
 int pmc_last_kernel_ms(pmc_ctx* ctx, float* ms);
 int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out);
 int pmc_reset_counters(pmc_ctx* ctx);
 /* Walk one ray on the device with the same traversal code the photon loop uses; k is normalised by the caller.
    Writes up to cap segments (cell index m or -1, length ds) and the number found to *n. */
 int pmc_trace_ray(pmc_ctx* ctx, const double r[3], const double k[3], int32_t* m, double* ds, int32_t cap, int32_t* n);
-/* tuning knobs (0 = default): threads per workgroup, workgroups; returns PMC_OK */
+/* tuning knobs (0 = default): threads per workgroup and workgroups of the persistent walk kernel */
 int pmc_set_launch(pmc_ctx* ctx, int32_t block, int32_t grid);
+/* number of photon histories kept in flight on the device (default 4 Mi; environment PMC_NUM_SLOTS) */
+int pmc_set_num_slots(pmc_ctx* ctx, int64_t num_slots);
+/* HIP-event timing of the most recent pmc_run_primary: whole segment, sum over its walk-kernel launches, sum over
+   its transition-kernel launches, and the number of generations (walk + transition launch pairs) */
+int pmc_last_timing(pmc_ctx* ctx, float* total_ms, float* walk_ms, float* transition_ms, int32_t* generations);
 
 #ifdef __cplusplus
 }

@@ -1,24 +1,31 @@
-// pmc_api.hip -- the extern "C" ABI of include/pmc.h: scene upload, launches, downloads.
+// pmc_api.hip -- the extern "C" ABI of include/pmc.h: scene upload, the generation loop, downloads.
 //
 // pmc_create turns the reference-shaped tables of pmc_scene into the device layout of pmc_device.h.  For the
 // octree this means: verify that every node box is consistent with one per-axis dyadic coordinate table (true for
 // any tree built by recursive midpoint subdivision, OctTreeNode.cpp:22-33), build that table from the reference's
-// own doubles, and replace the per-wall neighbour lists by one link per wall (the same-size-or-coarser neighbour
-// leaf, or the internal node that covers the finer neighbours).  The reference lists themselves are uploaded too,
-// re-indexed by cell, for the exact fallback path.
+// own doubles, and replace the per-wall neighbour lists by four links per wall (per quadrant of the wall: the
+// neighbour leaf covering it, or the internal node below which finer neighbours are found).  The reference lists
+// themselves are uploaded too, re-indexed by cell, for the exact fallback path.
+//
+// pmc_run_primary drives the two kernels of pmc_kernels.hip in generations over a pool of packet slots.
 
 #include "pmc_device.h"
 #include "../../include/pmc_layout.h"
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 extern "C" hipError_t pmcUploadScene(int slot, const DevScene* scene, hipStream_t stream);
-extern "C" hipError_t pmcLaunchPrimary(int slot, int gridKind, uint64_t first, uint64_t count, uint64_t seed, int grid,
-                                       int block, size_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds);
+extern "C" int pmcWalkBlocksPerCU(int gridKind, int block, size_t ldsBytes);
+extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int numSlots, int grid, int block, size_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t pmcLaunchTransition(int slot, int numSlots, uint64_t first, uint64_t count, uint64_t seed, int initial,
+                                          size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchTrace(int slot, int gridKind, const double r[3], const double k[3], int32_t* m, double* ds,
                                      int32_t cap, int32_t* n, size_t ldsBytes, hipStream_t stream);
 
@@ -52,17 +59,22 @@ struct pmc_ctx
     int slot{-1};
     bool sceneDirty{true};
     hipStream_t stream{nullptr};
-    hipEvent_t evStart{nullptr}, evStop{nullptr};
+    hipEvent_t evStart{nullptr}, evStop{nullptr}, evA{nullptr}, evB{nullptr}, evC{nullptr};
     bool timed{false};
+    float totalMs{0}, walkMs{0}, transitionMs{0};
+    int generations{0};
     DevScene dev{};
     std::vector<void*> allocations;
+    std::vector<void*> slotAllocations;
     double* frames{nullptr};
-    bool ownFrames{true};
     int64_t frameSize{0};
-    size_t ldsBytes{0};
+    size_t walkLds{0}, transitionLds{0};
     int block{256};
     int grid{0};
-    int64_t statLanes{0};
+    int numCU{256};
+    int64_t numSlots{0};         // requested pool size
+    int64_t allocatedSlots{0};   // size of the allocated slot arrays
+    unsigned long long* pinned{nullptr};
 
     template<typename T> int upload(const T* host, size_t count, const T** out)
     {
@@ -77,14 +89,14 @@ struct pmc_ctx
         *out = static_cast<const T*>(d);
         return PMC_OK;
     }
-    template<typename T> int allocate(size_t count, T** out, bool zero)
+    template<typename T> int allocate(size_t count, T** out, bool zero, std::vector<void*>* owner = nullptr)
     {
         *out = nullptr;
         if (!count) return PMC_OK;
         void* d = nullptr;
         hipError_t e = hipMalloc(&d, count * sizeof(T));
         if (e != hipSuccess) return hipFail(e, "hipMalloc");
-        allocations.push_back(d);
+        (owner ? *owner : allocations).push_back(d);
         if (zero)
         {
             e = hipMemset(d, 0, count * sizeof(T));
@@ -173,9 +185,7 @@ namespace
         };
         T.rootLink = linkOf(0);
 
-        // node lookup by (level, fine coordinates) for the same-size neighbour search: walk up/down the tree
-        // neighbour of node `id` through `wall`: the deepest node at level <= level(id) whose box covers the region
-        // adjacent to the wall; found by descending from the root towards a point just across the wall centre
+        // the node at level <= level(id) that covers the region just across `wall` of node id (-1: outside the grid)
         auto covering = [&](int id, int wall) -> int {
             int axis = wall >> 1, side = wall & 1;
             int size = 1 << (maxLevel - g.node_level[id]);
@@ -224,12 +234,30 @@ namespace
             rec.density = density[m];
             for (int wall = 0; wall < 6; ++wall)
             {
-                rec.link[wall] = linkOf(covering(id, wall));
+                const int axis = wall >> 1, side = wall & 1;
+                const int t1 = axis == 0 ? 1 : 0;  // transverse axes, x before y before z
+                const int t2 = axis == 2 ? 1 : 2;
+                const int N = covering(id, wall);
+                for (int q = 0; q < 4; ++q)
+                {
+                    int32_t link;
+                    if (N < 0)
+                        link = PMC_LINK_NONE;
+                    else if (g.node_first_child[N] < 0 || g.node_level[N] < g.node_level[id])
+                        link = linkOf(N);  // same-size or coarser leaf (an internal node here cannot be coarser)
+                    else
+                    {
+                        // same-level internal node: its child adjacent to the wall in quadrant q
+                        int l = ((side ? 0 : 1) << axis) | ((q & 1) << t1) | (((q >> 1) & 1) << t2);
+                        link = linkOf(g.node_first_child[N] + l);
+                    }
+                    rec.link[wall][q] = link;
+                }
                 // the reference's neighbour list of this leaf, re-indexed by cell
                 T.nbrStart[6 * size_t(m) + wall] = (int32_t)T.nbrList.size();
-                for (int q = g.nbr_start[6 * size_t(id) + wall]; q < g.nbr_start[6 * size_t(id) + wall + 1]; ++q)
+                for (int qq = g.nbr_start[6 * size_t(id) + wall]; qq < g.nbr_start[6 * size_t(id) + wall + 1]; ++qq)
                 {
-                    int nb = g.nbr_list[q];
+                    int nb = g.nbr_list[qq];
                     if (g.node_first_child[nb] >= 0)
                         return fail(PMC_ERR_INVALID, "neighbour list of a leaf contains a non-leaf node");
                     T.nbrList.push_back(g.node_cell[nb]);
@@ -237,6 +265,38 @@ namespace
             }
         }
         T.nbrStart[6 * size_t(numCells)] = (int32_t)T.nbrList.size();
+        return PMC_OK;
+    }
+
+    int allocateSlots(pmc_ctx* ctx, int64_t n)
+    {
+        hipSetDevice(ctx->device);
+        for (void* p : ctx->slotAllocations) hipFree(p);
+        ctx->slotAllocations.clear();
+        SlotArrays& A = ctx->dev.slots;
+        std::memset(&A, 0, sizeof(A));
+        auto& own = ctx->slotAllocations;
+        int rc;
+        double** dbl[] = {&A.rx, &A.ry, &A.rz, &A.kx, &A.ky, &A.kz, &A.lambda, &A.W, &A.Lthreshold, &A.pW, &A.target,
+                          &A.taupath, &A.rngSpare, &A.tau, &A.sint, &A.nint};
+        for (double** d : dbl)
+            if ((rc = ctx->allocate<double>(n, d, false, &own))) return rc;
+        if ((rc = ctx->allocate<uint64_t>(n, &A.history, false, &own))) return rc;
+        if ((rc = ctx->allocate<uint32_t>(n, &A.rngBlock, false, &own))) return rc;
+        int32_t** ints[] = {&A.dustIndex, &A.mode, &A.nscatt, &A.pscatt, &A.cellhint, &A.mint};
+        for (int32_t** d : ints)
+            if ((rc = ctx->allocate<int32_t>(n, d, true, &own))) return rc;
+        if ((rc = ctx->allocate<int32_t>(size_t(n) * PMC_MAX_INSTRUMENTS, &A.ell, true, &own))) return rc;
+        if ((rc = ctx->allocate<int32_t>(size_t(n) * PMC_MAX_INSTRUMENTS, &A.nstat, true, &own))) return rc;
+        if (ctx->dev.any_stats)
+        {
+            size_t entries = size_t(ctx->dev.num_instruments) * PMC_STAT_CAP * size_t(n);
+            if ((rc = ctx->allocate<int32_t>(entries, &A.statBin, false, &own))) return rc;
+            if ((rc = ctx->allocate<double>(entries, &A.statW, false, &own))) return rc;
+        }
+        A.num_slots = n;
+        ctx->allocatedSlots = n;
+        ctx->sceneDirty = true;
         return PMC_OK;
     }
 }
@@ -263,9 +323,12 @@ void pmc_destroy(pmc_ctx* ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (void* p : ctx->allocations) hipFree(p);
-    if (ctx->evStart) hipEventDestroy(ctx->evStart);
-    if (ctx->evStop) hipEventDestroy(ctx->evStop);
+    for (void* p : ctx->slotAllocations) hipFree(p);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
+    for (hipEvent_t e : {ctx->evStart, ctx->evStop, ctx->evA, ctx->evB, ctx->evC})
+        if (e) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->slot >= 0) g_slotUsed[ctx->slot] = false;
     delete ctx;
@@ -308,8 +371,10 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         return code;
     };
     if (hipStreamCreate(&ctx->stream) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipStreamCreate failed"));
-    if (hipEventCreate(&ctx->evStart) != hipSuccess || hipEventCreate(&ctx->evStop) != hipSuccess)
-        return bail(fail(PMC_ERR_DEVICE, "hipEventCreate failed"));
+    for (hipEvent_t* ev : {&ctx->evStart, &ctx->evStop, &ctx->evA, &ctx->evB, &ctx->evC})
+        if (hipEventCreate(ev) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipEventCreate failed"));
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), 16 * sizeof(unsigned long long)) != hipSuccess)
+        return bail(fail(PMC_ERR_DEVICE, "hipHostMalloc failed"));
 
     DevScene& D = ctx->dev;
     const pmc_grid& g = scene->grid;
@@ -318,8 +383,6 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     D.gx1 = g.xmax, D.gy1 = g.ymax, D.gz1 = g.zmax;
     D.eps = g.eps;
     D.num_cells = g.num_cells;
-    int ldsDoubles = 0;
-    D.lds_grid_off = 0;
     if (g.kind == PMC_GRID_CARTESIAN)
     {
         D.nx = g.nx, D.ny = g.ny, D.nz = g.nz;
@@ -327,7 +390,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if ((rc = ctx->upload(g.yv, g.ny + 1, &D.yv))) return bail(rc);
         if ((rc = ctx->upload(g.zv, g.nz + 1, &D.zv))) return bail(rc);
         if ((rc = ctx->upload(scene->medium.number_density, g.num_cells, &D.cell_density))) return bail(rc);
-        ldsDoubles += (g.nx + 1) + (g.ny + 1) + (g.nz + 1);
+        D.lds_grid_len = (g.nx + 1) + (g.ny + 1) + (g.nz + 1);
         D.lmax = 0;
     }
     else
@@ -341,7 +404,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if ((rc = ctx->upload(T.internals.data(), T.internals.size(), &D.nodes))) return bail(rc);
         if ((rc = ctx->upload(T.nbrStart.data(), T.nbrStart.size(), &D.nbr_start))) return bail(rc);
         if ((rc = ctx->upload(T.nbrList.data(), T.nbrList.size(), &D.nbr_list))) return bail(rc);
-        ldsDoubles += 3 * T.tabn;
+        D.lds_grid_len = 3 * T.tabn;
     }
 
     // ---- medium
@@ -351,9 +414,11 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     if ((rc = ctx->upload(med.sigma_ext, med.num_lambda, &D.sigma_ext))) return bail(rc);
     if ((rc = ctx->upload(med.sigma_sca, med.num_lambda, &D.sigma_sca))) return bail(rc);
     if ((rc = ctx->upload(med.asymmpar, med.num_lambda, &D.asymmpar))) return bail(rc);
-    D.lds_dust_off = ldsDoubles;
     D.dust_in_lds = med.num_lambda <= 2048;  // <= 64 KiB for the four tables
-    if (D.dust_in_lds) ldsDoubles += 4 * med.num_lambda;
+    int walkDoubles = D.lds_grid_len + (D.dust_in_lds ? med.num_lambda : 0);
+    int transDoubles = 0;
+    D.lds_dust_off = 0;
+    if (D.dust_in_lds) transDoubles += 4 * med.num_lambda;
 
     D.force_scattering = scene->options.force_scattering;
     D.min_weight_reduction = scene->options.min_weight_reduction;
@@ -375,14 +440,16 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     D.bias_kind = src.bias_kind;
     D.bias_min = src.bias_min;
     D.bias_max = src.bias_max;
-    D.lds_src_off = ldsDoubles;
+    D.lds_src_off = transDoubles;
     if (src.kind == PMC_SOURCE_SERSIC)
     {
         if (src.sersic_n < 2) return bail(fail(PMC_ERR_INVALID, "Sersic source without tables"));
         if ((rc = ctx->upload(src.sersic_s, src.sersic_n, &D.sersic_s))) return bail(rc);
         if ((rc = ctx->upload(src.sersic_M, src.sersic_n, &D.sersic_M))) return bail(rc);
-        ldsDoubles += 2 * src.sersic_n;
+        transDoubles += 2 * src.sersic_n;
     }
+    else if (src.kind != PMC_SOURCE_POINT && src.kind != PMC_SOURCE_UNIFORM_BOX)
+        return bail(fail(PMC_ERR_UNSUPPORTED, "unsupported source kind"));
     if (src.lambda_mode == PMC_LAMBDA_OLIGO)
     {
         if (src.num_oligo < 1) return bail(fail(PMC_ERR_INVALID, "oligochromatic source without wavelengths"));
@@ -401,7 +468,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
 
     // ---- instruments and frame layout
     D.num_instruments = scene->num_instruments;
-    D.lds_sed_off = ldsDoubles;
+    D.lds_sed_off = transDoubles;
     int sedDoubles = 0;
     D.any_stats = 0;
     for (int i = 0; i < scene->num_instruments; ++i)
@@ -434,26 +501,35 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if (d.record_stats) D.any_stats = 1;
     }
     D.lds_sed_len = sedDoubles;
-    ldsDoubles += sedDoubles;
-    D.lds_total = ldsDoubles;
-    ctx->ldsBytes = size_t(ldsDoubles) * sizeof(double);
-    if (ctx->ldsBytes > 160 * 1024)
-        return bail(fail(PMC_ERR_UNSUPPORTED, "scene tables need " + std::to_string(ctx->ldsBytes) + " bytes of LDS (> 160 KiB)"));
+    transDoubles += sedDoubles;
+    transDoubles += 2 * 256;  // hot-bin table of the transition kernel (pmc_transition.inc HOT_BINS keys + values)
+    D.lds_total_transition = transDoubles;
+    D.lds_total_walk = walkDoubles;
+    ctx->walkLds = size_t(walkDoubles) * sizeof(double);
+    ctx->transitionLds = size_t(transDoubles) * sizeof(double);
+    if (ctx->walkLds > 160 * 1024 || ctx->transitionLds > 160 * 1024)
+        return bail(fail(PMC_ERR_UNSUPPORTED, "scene tables need more than 160 KiB of LDS"));
+    if (pmcConfigureKernels(ctx->walkLds, ctx->transitionLds) != hipSuccess)
+        return bail(fail(PMC_ERR_DEVICE, "hipFuncSetAttribute failed"));
 
-    // ---- launch geometry: persistent workgroups, as many as stay resident
+    // ---- launch geometry of the persistent walk kernel: as many workgroups as stay resident
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipGetDeviceProperties failed"));
-    int perCU = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / std::max<size_t>(ctx->ldsBytes, 1)));
-    perCU = std::min(perCU, 4);
-    ctx->grid = prop.multiProcessorCount * perCU;
+    ctx->numCU = prop.multiProcessorCount;
     ctx->block = 256;
-    ctx->statLanes = 0;
+    int perCU = pmcWalkBlocksPerCU(D.grid_kind, ctx->block, ctx->walkLds);
+    if (perCU < 1) perCU = 1;
+    ctx->grid = ctx->numCU * perCU;
+
+    // ---- packet slots
+    int64_t slots = 4 * 1024 * 1024;
+    if (const char* env = getenv("PMC_NUM_SLOTS")) slots = std::max<int64_t>(1024, atoll(env));
+    ctx->numSlots = slots;
 
     // ---- outputs
     if ((rc = ctx->allocate<double>(ctx->frameSize, &ctx->frames, true))) return bail(rc);
     D.frames = ctx->frames;
-    if ((rc = ctx->allocate<unsigned long long>(16, &D.counters, true))) return bail(rc);
-    D.history_counter = D.counters + 15;
+    if ((rc = ctx->allocate<unsigned long long>(32, &D.counters, true))) return bail(rc);
     *out = ctx;
     return PMC_OK;
 }
@@ -470,12 +546,19 @@ int pmc_set_launch(pmc_ctx* ctx, int32_t block, int32_t grid)
     return PMC_OK;
 }
 
+int pmc_set_num_slots(pmc_ctx* ctx, int64_t num_slots)
+{
+    if (!ctx) return fail(PMC_ERR_INVALID, "null context");
+    if (num_slots < 64 || num_slots > (int64_t(1) << 30)) return fail(PMC_ERR_INVALID, "num_slots out of range");
+    ctx->numSlots = num_slots;
+    return PMC_OK;
+}
+
 int pmc_bind_frames(pmc_ctx* ctx, double* device_ptr, int64_t num_doubles)
 {
     if (!ctx || !device_ptr) return fail(PMC_ERR_INVALID, "null argument");
     if (num_doubles != ctx->frameSize) return fail(PMC_ERR_INVALID, "frame buffer size mismatch");
     ctx->frames = device_ptr;
-    ctx->ownFrames = false;
     ctx->dev.frames = device_ptr;
     ctx->sceneDirty = true;
     return PMC_OK;
@@ -495,30 +578,60 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     if (count == 0) return PMC_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     DevScene& D = ctx->dev;
-    // per-lane contribution lists for the statistics
-    const int64_t lanes = int64_t(ctx->grid) * ctx->block;
-    if (D.any_stats && lanes != ctx->statLanes)
+    const int64_t want = std::min<int64_t>(ctx->numSlots, (int64_t)std::min<uint64_t>(count, uint64_t(1) << 30));
+    if (want > ctx->allocatedSlots)
     {
-        size_t entries = size_t(D.num_instruments) * PMC_STAT_CAP * size_t(lanes);
-        int rc;
-        if ((rc = ctx->allocate<int32_t>(entries, &D.stat_bin, false))) return rc;
-        if ((rc = ctx->allocate<double>(entries, &D.stat_w, false))) return rc;
-        ctx->statLanes = lanes;
-        ctx->sceneDirty = true;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        int rc = allocateSlots(ctx, want);
+        if (rc) return rc;
     }
-    if (D.stat_lanes != lanes) ctx->sceneDirty = true;
-    D.stat_lanes = lanes;
+    const int numSlots = (int)want;
     if (ctx->sceneDirty)
     {
-        // make sure no earlier launch of this context still reads the slot, then refresh it
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(pmcUploadScene(ctx->slot, &D, ctx->stream));
         ctx->sceneDirty = false;
     }
-    HIP_TRY(hipMemsetAsync(D.history_counter, 0, sizeof(unsigned long long), ctx->stream));
-    HIP_TRY(hipEventRecord(ctx->evStart, ctx->stream));
-    HIP_TRY(pmcLaunchPrimary(ctx->slot, D.grid_kind, first, count, seed, ctx->grid, ctx->block, ctx->ldsBytes, ctx->stream));
-    HIP_TRY(hipEventRecord(ctx->evStop, ctx->stream));
+    hipStream_t st = ctx->stream;
+    unsigned long long* ctr = D.counters;
+    float walkMs = 0, transMs = 0;
+    int generations = 0;
+    HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_HISTORY, 0, 3 * sizeof(unsigned long long), st));
+    HIP_TRY(hipEventRecord(ctx->evStart, st));
+    HIP_TRY(hipEventRecord(ctx->evB, st));
+    HIP_TRY(pmcLaunchTransition(ctx->slot, numSlots, first, count, seed, 1, ctx->transitionLds, st));
+    HIP_TRY(hipEventRecord(ctx->evC, st));
+    bool haveWalk = false;
+    const int walkGrid = std::max(1, std::min(ctx->grid, (numSlots + ctx->block - 1) / ctx->block));
+    while (true)
+    {
+        HIP_TRY(hipMemcpyAsync(ctx->pinned, ctr + PMC_CTR_NEXT, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        float ms = 0;
+        if (haveWalk)
+        {
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->evA, ctx->evB));
+            walkMs += ms;
+        }
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->evB, ctx->evC));
+        transMs += ms;
+        const unsigned long long live = ctx->pinned[0];
+        if (live == 0) break;
+        ++generations;
+        HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK, 0, 2 * sizeof(unsigned long long), st));  // task cursor and live count
+        HIP_TRY(hipEventRecord(ctx->evA, st));
+        HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, numSlots, walkGrid, ctx->block, ctx->walkLds, st));
+        HIP_TRY(hipEventRecord(ctx->evB, st));
+        HIP_TRY(pmcLaunchTransition(ctx->slot, numSlots, first, count, seed, 0, ctx->transitionLds, st));
+        HIP_TRY(hipEventRecord(ctx->evC, st));
+        haveWalk = true;
+    }
+    HIP_TRY(hipEventRecord(ctx->evStop, st));
+    HIP_TRY(hipEventSynchronize(ctx->evStop));
+    HIP_TRY(hipEventElapsedTime(&ctx->totalMs, ctx->evStart, ctx->evStop));
+    ctx->walkMs = walkMs;
+    ctx->transitionMs = transMs;
+    ctx->generations = generations;
     ctx->timed = true;
     return PMC_OK;
 }
@@ -534,10 +647,19 @@ int pmc_sync(pmc_ctx* ctx)
 int pmc_last_kernel_ms(pmc_ctx* ctx, float* ms)
 {
     if (!ctx || !ms) return fail(PMC_ERR_INVALID, "null argument");
-    if (!ctx->timed) return fail(PMC_ERR_INVALID, "no kernel has been launched yet");
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipEventSynchronize(ctx->evStop));
-    HIP_TRY(hipEventElapsedTime(ms, ctx->evStart, ctx->evStop));
+    if (!ctx->timed) return fail(PMC_ERR_INVALID, "no segment has been run yet");
+    *ms = ctx->walkMs;
+    return PMC_OK;
+}
+
+int pmc_last_timing(pmc_ctx* ctx, float* total_ms, float* walk_ms, float* transition_ms, int32_t* generations)
+{
+    if (!ctx) return fail(PMC_ERR_INVALID, "null argument");
+    if (!ctx->timed) return fail(PMC_ERR_INVALID, "no segment has been run yet");
+    if (total_ms) *total_ms = ctx->totalMs;
+    if (walk_ms) *walk_ms = ctx->walkMs;
+    if (transition_ms) *transition_ms = ctx->transitionMs;
+    if (generations) *generations = ctx->generations;
     return PMC_OK;
 }
 
@@ -566,7 +688,7 @@ int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out)
     if (!ctx || !out) return fail(PMC_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    unsigned long long host[16];
+    unsigned long long host[32];
     HIP_TRY(hipMemcpy(host, ctx->dev.counters, sizeof(host), hipMemcpyDeviceToHost));
     out->histories = host[0];
     out->paths = host[1];
@@ -575,6 +697,14 @@ int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out)
     out->scatterings = host[4];
     out->stat_overflows = host[5];
     out->rewalk_visits = host[6];
+    if (getenv("PMC_PROFILE_DUMP"))
+        fprintf(stderr,
+                "PMC_PROFILE transition: cycles peel %llu pass1 %llu pass2 %llu launch %llu epilogue %llu | lanes peel %llu pass1 %llu "
+                "pass2 %llu launch %llu | waves %llu\n",
+                host[16], host[17], host[18], host[19], host[20], host[21], host[22], host[23], host[24], host[25]);
+    if (getenv("PMC_PROFILE_DUMP"))
+        fprintf(stderr, "PMC_PROFILE walk: refill_cycles %llu step_cycles %llu refills %llu wave_steps %llu lane_steps %llu\n", host[11],
+                host[12], host[13], host[14], host[15]);
     return PMC_OK;
 }
 
@@ -582,7 +712,7 @@ int pmc_reset_counters(pmc_ctx* ctx)
 {
     if (!ctx) return fail(PMC_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemsetAsync(ctx->dev.counters, 0, 15 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->dev.counters, 0, 32 * sizeof(unsigned long long), ctx->stream));
     return PMC_OK;
 }
 
@@ -596,7 +726,6 @@ int pmc_trace_ray(pmc_ctx* ctx, const double r[3], const double k[3], int32_t* m
     HIP_TRY(hipMalloc(&dm, sizeof(int32_t) * std::max(cap, 1)));
     HIP_TRY(hipMalloc(&dds, sizeof(double) * std::max(cap, 1)));
     HIP_TRY(hipMalloc(&dn, sizeof(int32_t)));
-    size_t gridLds = size_t(ctx->dev.lds_dust_off) * sizeof(double);
     hipError_t e = hipSuccess;
     if (ctx->sceneDirty)
     {
@@ -605,7 +734,7 @@ int pmc_trace_ray(pmc_ctx* ctx, const double r[3], const double k[3], int32_t* m
         if (e == hipSuccess) ctx->sceneDirty = false;
     }
     if (e == hipSuccess)
-        e = pmcLaunchTrace(ctx->slot, ctx->dev.grid_kind, r, k, dm, dds, cap, dn, gridLds, ctx->stream);
+        e = pmcLaunchTrace(ctx->slot, ctx->dev.grid_kind, r, k, dm, dds, cap, dn, ctx->walkLds, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     int rc = PMC_OK;
     if (e != hipSuccess)

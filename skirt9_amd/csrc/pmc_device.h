@@ -1,14 +1,17 @@
 // pmc_device.h -- device-side data layout of the MI355X photon-packet engine (shared by host API and kernels).
 //
-// HBM layout (all read-only during a segment, replicated per GPU):
-//   octree leaves   LeafRec[num_cells]   64-B aligned record per cell m: packed dyadic box code, number density,
-//                                        6 neighbour links (one per wall) -> ONE cache line per cell visit
-//   octree nodes    NodeRec[num_internal] 64-B record per non-leaf node: box code + 8 child links (descent only)
+// HBM layout (read-only during a segment, replicated per GPU):
+//   octree cells    LeafRec[num_cells]   one 128-byte record (= one L2 line) per cell m: dyadic box code, number
+//                                        density, and FOUR neighbour links per wall (one per quadrant of the wall),
+//                                        so that same-size, coarser and one-level-finer neighbours all cost ONE load
+//   octree nodes    NodeRec[num_internal] 64-byte record per non-leaf node: box code + 8 child links (descent only)
 //   coord table     double[3][2^Lmax+1]  the reference's wall coordinates per axis and dyadic index; staged in LDS
 //   neighbour CSR   int32                the reference's per-wall neighbour lists of every leaf, in the reference's
-//                                        order (cold: only read when a position lies exactly on a cell boundary)
+//                                        order (cold: only read when a position is not strictly inside a candidate)
 //   Cartesian       double xv/yv/zv (staged in LDS), density double[num_cells]
 //   dust tables     lambda_border/sigma_ext/sigma_sca/asymmpar double[num_lambda] (staged in LDS when small)
+// HBM, read-write:
+//   packet slots    struct-of-arrays over `num_slots` concurrently live photon histories (see SlotArrays)
 //   frames          double[frame_size]   detector arrays, accumulated with f64 atomics
 #ifndef PMC_DEVICE_H
 #define PMC_DEVICE_H
@@ -17,22 +20,22 @@
 #include <stdint.h>
 
 #define PMC_MAX_INSTRUMENTS 4
-#define PMC_MAX_CONTEXTS 8   // scene slots in constant memory (live contexts per process and device)
+#define PMC_MAX_CONTEXTS 8  // scene slots in constant memory (live contexts per process and device)
 #define PMC_MAX_LEVEL 12
-#define PMC_STAT_CAP 48  // per-history contribution list capacity per instrument (FluxRecorder statistics)
+#define PMC_STAT_CAP 48     // per-history contribution list capacity per instrument (FluxRecorder statistics)
 
 // link encoding: >= 0 leaf cell index m; -1 none (outside the grid); <= -2 internal node index = -2 - link
 #define PMC_LINK_NONE (-1)
 
 struct LeafRec
 {
-    uint64_t code;     // level (bits 48..51) | fx (bits 32..47) | fy (16..31) | fz (0..15): fine lower-corner indices
-    double   density;  // number density n[m]
-    int32_t  link[6];  // neighbour through wall w (same size or coarser leaf, or the internal node that covers finer ones)
-    int32_t  pad[2];
-    int32_t  pad2[4];
+    uint64_t code;        // level (bits 48..51) | fx (bits 32..47) | fy (16..31) | fz (0..15): fine lower-corner indices
+    double   density;     // number density n[m]
+    int32_t  link[6][4];  // wall w, quadrant q = (t1 >= c1) + 2 (t2 >= c2) of the two transverse coordinates (x before y
+                          // before z) against the cell centre: the neighbour covering that quadrant at level <= own+1
+    int32_t  pad[4];
 };
-static_assert(sizeof(LeafRec) == 64, "LeafRec must be one 64-byte record");
+static_assert(sizeof(LeafRec) == 128, "LeafRec must be one 128-byte record");
 
 struct NodeRec
 {
@@ -57,6 +60,40 @@ struct DevInstrument
     int64_t sed_offset, ifu_offset, wsed_offset, wifu_offset, npix;
     int32_t num_components;
     int32_t sed_lds_offset;  // offset (doubles) of this instrument's privatised SED block in LDS: [comp][ell] then [5][ell]
+};
+
+// One slot = one live photon history.  The walk kernel reads the task fields and writes the result fields; the
+// transition kernel owns everything else.  Struct-of-arrays: lane i of a wave touches element slot_i of each array.
+struct SlotArrays
+{
+    // packet (PhotonPacket.hpp:333-363)
+    double* rx; double* ry; double* rz;     // position
+    double* kx; double* ky; double* kz;     // propagation direction
+    double* lambda;                         // wavelength
+    double* W;                              // weight (luminosity = W / lambda)
+    double* Lthreshold;
+    double* pW;                             // weight of the peel-off packet under way
+    double* target;                         // pass 2: sampled optical depth; peel-off: taumax (MediumSystem.cpp:1199)
+    double* taupath;
+    uint64_t* history;
+    double*  rngSpare;
+    uint32_t* rngBlock;                     // (block << 1) | have
+    int32_t* dustIndex;                     // DustMix::indexForLambda(lambda)
+    int32_t* mode;                          // bits 0-1 walk mode, bits 2-4 instrument served by the peel-off, bit 5 alive
+    int32_t* nscatt;
+    int32_t* pscatt;                        // numScatt of the peel-off packet
+    int32_t* cellhint;                      // octree leaf that contains the position, or -1
+    int32_t* ell;                           // [PMC_MAX_INSTRUMENTS][num_slots] wavelength bin per instrument
+    int32_t* nstat;                         // [PMC_MAX_INSTRUMENTS][num_slots] length of the contribution list
+    // walk results
+    double* tau;                            // cumulative optical depth of the walk (inf: peel-off contribution is zero)
+    double* sint;                           // pass 2: interaction distance
+    double* nint;                           //         density of the interaction cell
+    int32_t* mint;                          //         interaction cell (-1: none)
+    // per-history contribution lists: bin[(inst*CAP + e)*num_slots + slot], w likewise
+    int32_t* statBin;
+    double*  statW;
+    int64_t  num_slots;
 };
 
 struct DevScene
@@ -112,17 +149,20 @@ struct DevScene
     int32_t num_instruments;
     DevInstrument inst[PMC_MAX_INSTRUMENTS];
     int32_t any_stats;
-    // ---- outputs
+    // ---- outputs and work state
     double* frames;
-    unsigned long long* counters;         // pmc_counter_values as 6 x u64
-    unsigned long long* history_counter;  // next history offset to hand out
-    // per-lane contribution lists: bin[(inst*CAP + e)*lanes + lane], w likewise
-    int32_t* stat_bin;
-    double*  stat_w;
-    int64_t  stat_lanes;
+    unsigned long long* counters;  // [0..6] pmc_counter_values, [8] next history offset, [9] next walk task,
+                                   // [10] length of the next active list
+    SlotArrays slots;
     // ---- LDS carve-up (in doubles from the start of dynamic LDS)
-    int32_t lds_grid_off, lds_dust_off, lds_src_off, lds_sed_off, lds_sed_len, lds_total;
+    int32_t lds_grid_len;          // walk + transition kernels: grid tables at offset 0
+    int32_t lds_dust_off;          // both: dust tables (walk kernel uses sigma_ext only)
+    int32_t lds_src_off, lds_sed_off, lds_sed_len, lds_total_transition, lds_total_walk;
     int32_t dust_in_lds;
 };
+
+#define PMC_CTR_HISTORY 8
+#define PMC_CTR_TASK 9
+#define PMC_CTR_NEXT 10
 
 #endif

@@ -17,7 +17,8 @@ _LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 # every symbol include/pmc.h declares
 SYMBOLS = ["pmc_abi_version", "pmc_last_error", "pmc_frame_layout_of", "pmc_create", "pmc_destroy", "pmc_bind_frames",
            "pmc_clear_frames", "pmc_run_primary", "pmc_sync", "pmc_download", "pmc_frames_device", "pmc_frames_size",
-           "pmc_last_kernel_ms", "pmc_counters", "pmc_reset_counters", "pmc_trace_ray", "pmc_set_launch"]
+           "pmc_last_kernel_ms", "pmc_counters", "pmc_reset_counters", "pmc_trace_ray", "pmc_set_launch",
+           "pmc_set_num_slots", "pmc_last_timing"]
 
 _lib = None
 
@@ -50,6 +51,9 @@ def lib():
         L.pmc_reset_counters.argtypes = [C.c_void_p]
         L.pmc_trace_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.pmc_set_launch.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.pmc_set_num_slots.argtypes = [C.c_void_p, C.c_int64]
+        L.pmc_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                      C.POINTER(C.c_int32)]
         _lib = L
     return _lib
 
@@ -108,6 +112,16 @@ class Engine:
         ms = C.c_float(0)
         _check(lib().pmc_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def set_num_slots(self, n):
+        _check(lib().pmc_set_num_slots(self._h, int(n)))
+
+    def last_timing(self):
+        """HIP-event times of the last segment: dict(total_ms, walk_ms, transition_ms, generations)"""
+        t, w, x, g = C.c_float(0), C.c_float(0), C.c_float(0), C.c_int32(0)
+        _check(lib().pmc_last_timing(self._h, C.byref(t), C.byref(w), C.byref(x), C.byref(g)))
+        return {"total_ms": float(t.value), "walk_ms": float(w.value), "transition_ms": float(x.value),
+                "generations": int(g.value)}
 
     def download(self):
         out = np.empty(self.frame_size, dtype=np.float64)
