@@ -21,6 +21,12 @@ skirt9_amd/lib/libpmc.so: $(wildcard skirt9_amd/csrc/*.hip) $(wildcard skirt9_am
 	@mkdir -p skirt9_amd/lib
 	$(HIPCC) $(HIPFLAGS) -shared $(wildcard skirt9_amd/csrc/*.hip) -o $@
 
+# tuning aid: the same engine with in-kernel cycle stamps (PMC_LIBRARY=.../libpmc_prof.so PMC_PROFILE_DUMP=1)
+profile-lib: skirt9_amd/lib/libpmc_prof.so
+skirt9_amd/lib/libpmc_prof.so: $(wildcard skirt9_amd/csrc/*.hip) $(wildcard skirt9_amd/csrc/*.h) $(wildcard skirt9_amd/csrc/*.inc) $(wildcard include/*.h)
+	@mkdir -p skirt9_amd/lib
+	$(HIPCC) $(HIPFLAGS) -DPMC_PROFILE -shared $(wildcard skirt9_amd/csrc/*.hip) -o $@
+
 skirt9_amd/lib/skirt_mi355x: skirt9_amd/host/main.cpp skirt9_amd/lib/libskirthost.so skirt9_amd/lib/libpmc.so
 	$(CXX) $(CXXFLAGS) skirt9_amd/host/main.cpp -Lskirt9_amd/lib -lskirthost -lpmc -Wl,-rpath,'$$ORIGIN' -o $@
 

@@ -23,9 +23,12 @@
 extern "C" hipError_t pmcUploadScene(int slot, const DevScene* scene, hipStream_t stream);
 extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds);
 extern "C" int pmcWalkBlocksPerCU(int gridKind, int block, size_t ldsBytes);
-extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int numSlots, int grid, int block, size_t ldsBytes, hipStream_t stream);
-extern "C" hipError_t pmcLaunchTransition(int slot, int numSlots, uint64_t first, uint64_t count, uint64_t seed, int initial,
+extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int taskBase, int taskCounter, int grid, int block, size_t ldsBytes,
+                                    hipStream_t stream);
+extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int groupCounters, uint64_t seed,
                                           size_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int groupCounters, uint64_t first,
+                                      uint64_t count, uint64_t seed, int initial, int grid, size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchTrace(int slot, int gridKind, const double r[3], const double k[3], int32_t* m, double* ds,
                                      int32_t cap, int32_t* n, size_t ldsBytes, hipStream_t stream);
 
@@ -59,7 +62,11 @@ struct pmc_ctx
     int slot{-1};
     bool sceneDirty{true};
     hipStream_t stream{nullptr};
-    hipEvent_t evStart{nullptr}, evStop{nullptr}, evA{nullptr}, evB{nullptr}, evC{nullptr};
+    // slot groups: the generations of group g are enqueued on groupStream[g] (group 0 uses `stream`)
+    int numGroups{2};
+    hipStream_t groupStream[PMC_MAX_GROUPS]{};
+    hipEvent_t evA[PMC_MAX_GROUPS]{}, evB[PMC_MAX_GROUPS]{}, evC[PMC_MAX_GROUPS]{};
+    hipEvent_t evStart{nullptr}, evStop{nullptr};
     bool timed{false};
     float totalMs{0}, walkMs{0}, transitionMs{0};
     int generations{0};
@@ -118,7 +125,7 @@ namespace
         std::vector<LeafRec> leaves;     // by cell index m
         std::vector<NodeRec> internals;  // by internal index
         std::vector<int32_t> nbrStart, nbrList;
-        int32_t rootLink{0};
+        uint32_t rootLink{0};
     };
 
     int buildTree(const pmc_grid& g, const double* density, TreeBuild& T)
@@ -176,12 +183,19 @@ namespace
                 return fail(PMC_ERR_UNSUPPORTED,
                             "octree node boxes are not consistent with a dyadic coordinate table (node " + std::to_string(id) + ")");
         }
+        // box code (pmc_device.h LeafRec::code): LDS byte offsets of the three lower wall entries + size exponent
         auto code = [&](int id) -> uint64_t {
-            return ((uint64_t)g.node_level[id] << 48) | ((uint64_t)fx[id] << 32) | ((uint64_t)fy[id] << 16) | (uint64_t)fz[id];
+            const uint64_t ox = 8ull * uint64_t(fx[id]);
+            const uint64_t oy = 8ull * uint64_t(T.tabn + fy[id]);
+            const uint64_t oz = 8ull * uint64_t(2 * T.tabn + fz[id]);
+            return ox | (oy << 20) | (oz << 40) | ((uint64_t)(maxLevel - g.node_level[id]) << 60);
         };
-        auto linkOf = [&](int id) -> int32_t {
+        // link word (pmc_device.h): size exponent | index << 4 | node flag
+        auto linkOf = [&](int id) -> uint32_t {
             if (id < 0) return PMC_LINK_NONE;
-            return g.node_first_child[id] < 0 ? g.node_cell[id] : (-2 - internalIndex[id]);
+            const uint32_t e = uint32_t(maxLevel - g.node_level[id]);
+            return g.node_first_child[id] < 0 ? (e | (uint32_t(g.node_cell[id]) << 4))
+                                              : (e | (uint32_t(internalIndex[id]) << 4) | PMC_LINK_NODE);
         };
         T.rootLink = linkOf(0);
 
@@ -240,7 +254,7 @@ namespace
                 const int N = covering(id, wall);
                 for (int q = 0; q < 4; ++q)
                 {
-                    int32_t link;
+                    uint32_t link;
                     if (N < 0)
                         link = PMC_LINK_NONE;
                     else if (g.node_first_child[N] < 0 || g.node_level[N] < g.node_level[id])
@@ -294,6 +308,15 @@ namespace
             if ((rc = ctx->allocate<int32_t>(entries, &A.statBin, false, &own))) return rc;
             if ((rc = ctx->allocate<double>(entries, &A.statW, false, &own))) return rc;
         }
+        TaskArrays& K = ctx->dev.tasks;
+        std::memset(&K, 0, sizeof(K));
+        double** tdbl[] = {&K.rx, &K.ry, &K.rz, &K.kx, &K.ky, &K.kz, &K.ikx, &K.iky, &K.ikz, &K.s0, &K.ds, &K.target, &K.sext};
+        for (double** d : tdbl)
+            if ((rc = ctx->allocate<double>(n, d, false, &own))) return rc;
+        int32_t** tints[] = {&K.slot, &K.cell, &K.cijk, &K.launchList};
+        for (int32_t** d : tints)
+            if ((rc = ctx->allocate<int32_t>(n, d, false, &own))) return rc;
+        if ((rc = ctx->allocate<uint32_t>(n, &K.bits, false, &own))) return rc;
         A.num_slots = n;
         ctx->allocatedSlots = n;
         ctx->sceneDirty = true;
@@ -327,8 +350,14 @@ void pmc_destroy(pmc_ctx* ctx)
     for (void* p : ctx->allocations) hipFree(p);
     for (void* p : ctx->slotAllocations) hipFree(p);
     if (ctx->pinned) hipHostFree(ctx->pinned);
-    for (hipEvent_t e : {ctx->evStart, ctx->evStop, ctx->evA, ctx->evB, ctx->evC})
+    for (hipEvent_t e : {ctx->evStart, ctx->evStop})
         if (e) hipEventDestroy(e);
+    for (int g = 0; g < PMC_MAX_GROUPS; ++g)
+    {
+        for (hipEvent_t e : {ctx->evA[g], ctx->evB[g], ctx->evC[g]})
+            if (e) hipEventDestroy(e);
+        if (g > 0 && ctx->groupStream[g]) hipStreamDestroy(ctx->groupStream[g]);
+    }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->slot >= 0) g_slotUsed[ctx->slot] = false;
     delete ctx;
@@ -371,8 +400,15 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         return code;
     };
     if (hipStreamCreate(&ctx->stream) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipStreamCreate failed"));
-    for (hipEvent_t* ev : {&ctx->evStart, &ctx->evStop, &ctx->evA, &ctx->evB, &ctx->evC})
+    ctx->groupStream[0] = ctx->stream;
+    for (int g = 1; g < PMC_MAX_GROUPS; ++g)
+        if (hipStreamCreate(&ctx->groupStream[g]) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipStreamCreate failed"));
+    for (hipEvent_t* ev : {&ctx->evStart, &ctx->evStop})
         if (hipEventCreate(ev) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipEventCreate failed"));
+    for (int g = 0; g < PMC_MAX_GROUPS; ++g)
+        for (hipEvent_t* ev : {&ctx->evA[g], &ctx->evB[g], &ctx->evC[g]})
+            if (hipEventCreate(ev) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipEventCreate failed"));
+    if (const char* env = getenv("PMC_NUM_GROUPS")) ctx->numGroups = std::min(PMC_MAX_GROUPS, std::max(1, atoi(env)));
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), 16 * sizeof(unsigned long long)) != hipSuccess)
         return bail(fail(PMC_ERR_DEVICE, "hipHostMalloc failed"));
 
@@ -392,6 +428,8 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if ((rc = ctx->upload(scene->medium.number_density, g.num_cells, &D.cell_density))) return bail(rc);
         D.lds_grid_len = (g.nx + 1) + (g.ny + 1) + (g.nz + 1);
         D.lmax = 0;
+        if (g.nx > 1024 || g.ny > 1024 || g.nz > 1024)
+            return bail(fail(PMC_ERR_UNSUPPORTED, "Cartesian grids with more than 1024 cells per axis are not supported"));
     }
     else
     {
@@ -399,6 +437,12 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if ((rc = buildTree(g, scene->medium.number_density, T))) return bail(rc);
         D.lmax = T.lmax;
         D.root_link = T.rootLink;
+        if (g.num_cells > (1 << 25) || T.internals.size() > (size_t(1) << 26))
+            return bail(fail(PMC_ERR_UNSUPPORTED, "octree with more than 2^25 cells (32-bit record offsets, 27-bit link index)"));
+        D.tab_stride_bytes = 8u * uint32_t(T.tabn);
+        D.fine_scale[0] = double(1 << T.lmax) / (g.xmax - g.xmin);
+        D.fine_scale[1] = double(1 << T.lmax) / (g.ymax - g.ymin);
+        D.fine_scale[2] = double(1 << T.lmax) / (g.zmax - g.zmin);
         if ((rc = ctx->upload(T.table.data(), T.table.size(), &D.coord_tab))) return bail(rc);
         if ((rc = ctx->upload(T.leaves.data(), T.leaves.size(), &D.leaves))) return bail(rc);
         if ((rc = ctx->upload(T.internals.data(), T.internals.size(), &D.nodes))) return bail(rc);
@@ -415,9 +459,9 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     if ((rc = ctx->upload(med.sigma_sca, med.num_lambda, &D.sigma_sca))) return bail(rc);
     if ((rc = ctx->upload(med.asymmpar, med.num_lambda, &D.asymmpar))) return bail(rc);
     D.dust_in_lds = med.num_lambda <= 2048;  // <= 64 KiB for the four tables
-    int walkDoubles = D.lds_grid_len + (D.dust_in_lds ? med.num_lambda : 0);
-    int transDoubles = 0;
-    D.lds_dust_off = 0;
+    int walkDoubles = D.lds_grid_len;
+    int transDoubles = D.lds_grid_len;  // the grid tables come first in every kernel
+    D.lds_dust_off = transDoubles;
     if (D.dust_in_lds) transDoubles += 4 * med.num_lambda;
 
     D.force_scattering = scene->options.force_scattering;
@@ -502,7 +546,10 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     }
     D.lds_sed_len = sedDoubles;
     transDoubles += sedDoubles;
-    transDoubles += 2 * 256;  // hot-bin table of the transition kernel (pmc_transition.inc HOT_BINS keys + values)
+    D.lds_hot_off = transDoubles;
+    transDoubles += 2 * 256;  // hot-bin table (pmc_transition.inc HOT_BINS keys + values)
+    D.lds_sort_off = transDoubles;
+    transDoubles += (64 + 2 * 1024 + 8) / 2;  // integer scratch: regrouping arrays and list-append counters
     D.lds_total_transition = transDoubles;
     D.lds_total_walk = walkDoubles;
     ctx->walkLds = size_t(walkDoubles) * sizeof(double);
@@ -519,6 +566,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     ctx->block = 256;
     int perCU = pmcWalkBlocksPerCU(D.grid_kind, ctx->block, ctx->walkLds);
     if (perCU < 1) perCU = 1;
+    if (const char* env = getenv("PMC_WALK_BLOCKS_PER_CU")) perCU = std::max(1, std::min(perCU, atoi(env)));  // tuning aid
     ctx->grid = ctx->numCU * perCU;
 
     // ---- packet slots
@@ -529,7 +577,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     // ---- outputs
     if ((rc = ctx->allocate<double>(ctx->frameSize, &ctx->frames, true))) return bail(rc);
     D.frames = ctx->frames;
-    if ((rc = ctx->allocate<unsigned long long>(32, &D.counters, true))) return bail(rc);
+    if ((rc = ctx->allocate<unsigned long long>(PMC_NUM_COUNTERS, &D.counters, true))) return bail(rc);
     *out = ctx;
     return PMC_OK;
 }
@@ -596,35 +644,84 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     unsigned long long* ctr = D.counters;
     float walkMs = 0, transMs = 0;
     int generations = 0;
-    HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_HISTORY, 0, 3 * sizeof(unsigned long long), st));
-    HIP_TRY(hipEventRecord(ctx->evStart, st));
-    HIP_TRY(hipEventRecord(ctx->evB, st));
-    HIP_TRY(pmcLaunchTransition(ctx->slot, numSlots, first, count, seed, 1, ctx->transitionLds, st));
-    HIP_TRY(hipEventRecord(ctx->evC, st));
-    bool haveWalk = false;
-    const int walkGrid = std::max(1, std::min(ctx->grid, (numSlots + ctx->block - 1) / ctx->block));
-    while (true)
+    // ---- slot groups: group g owns the slots [base[g], base[g] + size[g]) and the stream groupStream[g].  The
+    // generations of different groups are independent (histories come from one shared cursor), so while the host
+    // waits for one group the other groups' kernels keep the device busy: the tail of a walk kernel and the
+    // latency-bound transition kernel overlap with the walk kernel of another group.
+    int G = ctx->numGroups;
+    if (numSlots < G * 65536) G = 1;
+    int base[PMC_MAX_GROUPS], size[PMC_MAX_GROUPS];
+    bool active[PMC_MAX_GROUPS], haveWalk[PMC_MAX_GROUPS];
     {
-        HIP_TRY(hipMemcpyAsync(ctx->pinned, ctr + PMC_CTR_NEXT, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        float ms = 0;
-        if (haveWalk)
+        const int per = ((numSlots / G) + PMC_TRANSITION_ALIGN - 1) / PMC_TRANSITION_ALIGN * PMC_TRANSITION_ALIGN;
+        for (int g = 0; g < G; ++g)
         {
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->evA, ctx->evB));
+            base[g] = std::min(numSlots, g * per);
+            size[g] = std::min(per, numSlots - base[g]);
+            active[g] = size[g] > 0;
+            haveWalk[g] = false;
+        }
+    }
+    HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_HISTORY, 0, sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(0), 0, 4 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
+    HIP_TRY(hipEventRecord(ctx->evStart, st));
+    const int launchGrid = std::max(1, ctx->numCU * 4);
+    auto enqueue = [&](int g, bool initial) -> int {
+        hipStream_t sg = ctx->groupStream[g];
+        const int gc = PMC_CTR_TASK(g);
+        if (!initial)
+        {
+            HIP_TRY(hipMemsetAsync(ctr + gc, 0, sizeof(unsigned long long), sg));  // task cursor
+            HIP_TRY(hipEventRecord(ctx->evA[g], sg));
+            HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, base[g], gc, ctx->grid, ctx->block, ctx->walkLds, sg));
+            haveWalk[g] = true;
+            HIP_TRY(hipEventRecord(ctx->evB[g], sg));
+            // the lists of the next generation: number of tasks, ended histories, live slots
+            HIP_TRY(hipMemsetAsync(ctr + gc + 1, 0, 3 * sizeof(unsigned long long), sg));
+            HIP_TRY(pmcLaunchTransition(ctx->slot, D.grid_kind, base[g], size[g], gc, seed, ctx->transitionLds, sg));
+            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], gc, first, count, seed, 0, launchGrid,
+                                    ctx->transitionLds, sg));
+        }
+        else
+        {
+            if (g > 0) HIP_TRY(hipStreamWaitEvent(sg, ctx->evStart, 0));
+            HIP_TRY(hipEventRecord(ctx->evB[g], sg));
+            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], gc, first, count, seed, 1, (size[g] + 255) / 256,
+                                    ctx->transitionLds, sg));
+        }
+        HIP_TRY(hipEventRecord(ctx->evC[g], sg));
+        HIP_TRY(hipMemcpyAsync(ctx->pinned + g, ctr + PMC_CTR_LIVE(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
+        return PMC_OK;
+    };
+    for (int g = 0; g < G; ++g)
+        if (active[g])
+        {
+            int rc = enqueue(g, true);
+            if (rc) return rc;
+        }
+    int remaining = 0;
+    for (int g = 0; g < G; ++g) remaining += active[g] ? 1 : 0;
+    for (int g = 0; remaining > 0; g = (g + 1) % G)
+    {
+        if (!active[g]) continue;
+        HIP_TRY(hipStreamSynchronize(ctx->groupStream[g]));
+        float ms = 0;
+        if (haveWalk[g])
+        {
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->evA[g], ctx->evB[g]));
             walkMs += ms;
         }
-        HIP_TRY(hipEventElapsedTime(&ms, ctx->evB, ctx->evC));
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->evB[g], ctx->evC[g]));
         transMs += ms;
-        const unsigned long long live = ctx->pinned[0];
-        if (live == 0) break;
+        if (ctx->pinned[g] == 0)
+        {
+            active[g] = false;
+            --remaining;
+            continue;
+        }
         ++generations;
-        HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK, 0, 2 * sizeof(unsigned long long), st));  // task cursor and live count
-        HIP_TRY(hipEventRecord(ctx->evA, st));
-        HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, numSlots, walkGrid, ctx->block, ctx->walkLds, st));
-        HIP_TRY(hipEventRecord(ctx->evB, st));
-        HIP_TRY(pmcLaunchTransition(ctx->slot, numSlots, first, count, seed, 0, ctx->transitionLds, st));
-        HIP_TRY(hipEventRecord(ctx->evC, st));
-        haveWalk = true;
+        int rc = enqueue(g, false);
+        if (rc) return rc;
     }
     HIP_TRY(hipEventRecord(ctx->evStop, st));
     HIP_TRY(hipEventSynchronize(ctx->evStop));
@@ -688,7 +785,7 @@ int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out)
     if (!ctx || !out) return fail(PMC_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    unsigned long long host[32];
+    unsigned long long host[PMC_NUM_COUNTERS];
     HIP_TRY(hipMemcpy(host, ctx->dev.counters, sizeof(host), hipMemcpyDeviceToHost));
     out->histories = host[0];
     out->paths = host[1];
@@ -703,8 +800,12 @@ int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out)
                 "pass2 %llu launch %llu | waves %llu\n",
                 host[16], host[17], host[18], host[19], host[20], host[21], host[22], host[23], host[24], host[25]);
     if (getenv("PMC_PROFILE_DUMP"))
-        fprintf(stderr, "PMC_PROFILE walk: refill_cycles %llu step_cycles %llu refills %llu wave_steps %llu lane_steps %llu\n", host[11],
-                host[12], host[13], host[14], host[15]);
+        fprintf(stderr,
+                "PMC_PROFILE walk: service_cycles %llu step_cycles %llu services %llu wave_steps %llu lane_steps %llu slow_lanes %llu\n",
+                host[11], host[12], host[13], host[14], host[15], host[26]);
+    if (getenv("PMC_PROFILE_DUMP"))
+        fprintf(stderr, "PMC_PROFILE walk step phases (lane-0 cycles): pre-link %llu link-wait %llu descend %llu head-wait %llu enter %llu\n",
+                host[27], host[28], host[29], host[30], host[31]);
     return PMC_OK;
 }
 
@@ -712,7 +813,7 @@ int pmc_reset_counters(pmc_ctx* ctx)
 {
     if (!ctx) return fail(PMC_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemsetAsync(ctx->dev.counters, 0, 32 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->dev.counters, 0, PMC_NUM_COUNTERS * sizeof(unsigned long long), ctx->stream));
     return PMC_OK;
 }
 

@@ -24,14 +24,19 @@
 #define PMC_MAX_LEVEL 12
 #define PMC_STAT_CAP 48     // per-history contribution list capacity per instrument (FluxRecorder statistics)
 
-// link encoding: >= 0 leaf cell index m; -1 none (outside the grid); <= -2 internal node index = -2 - link
-#define PMC_LINK_NONE (-1)
+// link word (uint32): bits 0-3 size exponent e of the target box (its edge spans 2^e finest cells), bits 4-30 index,
+// bit 31 clear: leaf cell m = index; bit 31 set: internal node (NodeRec index); PMC_LINK_NONE: outside the grid
+#define PMC_LINK_NONE 0x7FFFFFFFu
+#define PMC_LINK_NODE 0x80000000u
+#define PMC_LINK_MAX_INDEX ((1u << 27) - 2u)
 
 struct LeafRec
 {
-    uint64_t code;        // level (bits 48..51) | fx (bits 32..47) | fy (16..31) | fz (0..15): fine lower-corner indices
+    uint64_t code;        // box code: bits 0-19 / 20-39 / 40-59 = byte offsets of the lower x / y / z wall coordinate in the
+                          // LDS table [3][2^Lmax+1] (i.e. 8*fx, 8*(tabn+fy), 8*(2 tabn+fz) with fine lower-corner indices
+                          // f), bits 60-63 = size exponent e = Lmax - level (the box spans 2^e finest cells per axis)
     double   density;     // number density n[m]
-    int32_t  link[6][4];  // wall w, quadrant q = (t1 >= c1) + 2 (t2 >= c2) of the two transverse coordinates (x before y
+    uint32_t link[6][4];  // wall w, quadrant q = (t1 >= c1) + 2 (t2 >= c2) of the two transverse coordinates (x before y
                           // before z) against the cell centre: the neighbour covering that quadrant at level <= own+1
     int32_t  pad[4];
 };
@@ -40,7 +45,7 @@ static_assert(sizeof(LeafRec) == 128, "LeafRec must be one 128-byte record");
 struct NodeRec
 {
     uint64_t code;
-    int32_t  child[8];
+    uint32_t child[8];
     int32_t  pad[6];
 };
 static_assert(sizeof(NodeRec) == 64, "NodeRec must be one 64-byte record");
@@ -96,6 +101,26 @@ struct SlotArrays
     int64_t  num_slots;
 };
 
+// Walk tasks: the transition and launch kernels start every walk (PathSegmentGenerator::moveInside, location of the
+// first cell, first exit distance) and append its start state here, compacted per slot group: task t of group g lives
+// at index group_base + t of every array.  The walk kernel loads a start state with independent loads (one memory
+// round trip) and never touches the slot arrays except to write the result of the walk.
+struct TaskArrays
+{
+    double* rx; double* ry; double* rz;     // position inside the grid (after moveInside)
+    double* kx; double* ky; double* kz;     // direction
+    double* ikx; double* iky; double* ikz;  // RN(1/k), NaN for an ignored axis
+    double* s0;                             // length of the initial segment outside the grid (0 if none)
+    double* ds;                             // exit distance of the first cell
+    double* target;                         // the walk stops in the first segment with tau > target
+    double* sext;                           // extinction cross section at the packet's wavelength
+    int32_t* slot;                          // slot that receives the result
+    int32_t* cell;                          // first cell
+    uint32_t* bits;                         // mode (bits 0-1) | exit axis (2-3) | direction signs (4-6) | size exponent (8-11)
+    int32_t* cijk;                          // Cartesian only: cell indices i | j << 10 | k << 20
+    int32_t* launchList;                    // slots whose history has ended (consumed by the launch kernel)
+};
+
 struct DevScene
 {
     // ---- grid
@@ -107,10 +132,12 @@ struct DevScene
     const double* zv;
     const double* cell_density;  // Cartesian
     int32_t lmax;                // octree: finest level; table entries per axis = (1 << lmax) + 1
+    double  fine_scale[3];       // octree: 2^lmax / extent per axis (position -> finest-level cell index)
+    uint32_t tab_stride_bytes;   // octree: bytes per axis of the coordinate table = 8 * ((1 << lmax) + 1)
     const double* coord_tab;     // [3][(1<<lmax)+1]
     const LeafRec* leaves;
     const NodeRec* nodes;
-    int32_t root_link;
+    uint32_t root_link;
     const int32_t* nbr_start;    // [6*num_cells + 1]
     const int32_t* nbr_list;     // leaf cell indices
     int32_t num_cells;
@@ -151,18 +178,26 @@ struct DevScene
     int32_t any_stats;
     // ---- outputs and work state
     double* frames;
-    unsigned long long* counters;  // [0..6] pmc_counter_values, [8] next history offset, [9] next walk task,
-                                   // [10] length of the next active list
+    unsigned long long* counters;  // [PMC_NUM_COUNTERS]: [0..6] pmc_counter_values, [8] next history offset,
+                                   // [11..31] profiling, [32 + 4 g ..] work counters of slot group g (PMC_CTR_*)
     SlotArrays slots;
-    // ---- LDS carve-up (in doubles from the start of dynamic LDS)
-    int32_t lds_grid_len;          // walk + transition kernels: grid tables at offset 0
-    int32_t lds_dust_off;          // both: dust tables (walk kernel uses sigma_ext only)
-    int32_t lds_src_off, lds_sed_off, lds_sed_len, lds_total_transition, lds_total_walk;
+    TaskArrays tasks;
+    // ---- LDS carve-up (in doubles from the start of dynamic LDS; no kernel has static LDS, so that the octree
+    //      coordinate table sits at LDS address 0 in all of them)
+    int32_t lds_grid_len;          // all kernels: grid tables at offset 0
+    int32_t lds_dust_off;          // transition/launch kernels: dust tables (the walk kernel keeps sigma_ext after the grid)
+    int32_t lds_src_off, lds_sed_off, lds_sed_len, lds_hot_off, lds_sort_off, lds_total_transition, lds_total_walk;
     int32_t dust_in_lds;
 };
 
+#define PMC_NUM_COUNTERS 64
 #define PMC_CTR_HISTORY 8
-#define PMC_CTR_TASK 9
-#define PMC_CTR_NEXT 10
+// per slot group g: cursor of the walk kernel over the task list, number of tasks, number of ended histories, live slots
+#define PMC_CTR_TASK(g) (32 + 4 * (g))
+#define PMC_CTR_NTASKS(g) (33 + 4 * (g))
+#define PMC_CTR_NLAUNCH(g) (34 + 4 * (g))
+#define PMC_CTR_LIVE(g) (35 + 4 * (g))
+#define PMC_MAX_GROUPS 4
+#define PMC_TRANSITION_ALIGN 1024  // slot groups start at multiples of the transition kernel's workgroup size
 
 #endif

@@ -1,0 +1,40 @@
+#!/bin/bash
+# tuning aid (GPU box): hardware-counter passes over one bench step, summed per kernel -> gpurun_out/pmc/summary.txt
+# usage: tools/pmc_passes.sh [bench args...]
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/pmc
+rm -rf $OUT; mkdir -p $OUT
+ARGS="${@:---steps 1 --warmup 0 --packets 2e7 --no-cpu-baseline}"
+PASSES=(
+"TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum"
+"TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"
+"TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_TAG_STALL_sum TCC_BUSY_sum"
+"TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum"
+"TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"
+"SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU"
+)
+i=0
+for p in "${PASSES[@]}"; do
+  i=$((i+1))
+  (cd /tmp && timeout 90 rocprofv3 --pmc $p --output-format csv -d $OUT/pass$i -- python $OLDPWD/bench.py $ARGS > $OUT/pass$i.log 2>&1)
+done
+python3 - <<'PY'
+import csv, glob, collections, os
+out = os.environ.get("OUTDIR", os.getcwd() + "/gpurun_out/pmc")
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+calls = collections.defaultdict(set)
+for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        import re
+        m = re.search(r"(walkKernel|transitionKernel|launchKernel|chase)", row["Kernel_Name"])
+        if not m: continue
+        k = m.group(1)
+        tot[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        calls[k].add((f, row["Dispatch_Id"]))
+with open(out + "/summary.txt", "w") as fh:
+    for k in sorted(tot):
+        fh.write(f"== {k}\n")
+        for c in sorted(tot[k]):
+            fh.write(f"   {c:45s} {tot[k][c]:.6e}\n")
+print(open(out + "/summary.txt").read())
+PY
