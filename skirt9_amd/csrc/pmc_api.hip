@@ -23,12 +23,13 @@
 extern "C" hipError_t pmcUploadScene(int slot, const DevScene* scene, hipStream_t stream);
 extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds);
 extern "C" int pmcWalkBlocksPerCU(int gridKind, int block, size_t ldsBytes);
-extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int taskBase, int taskCounter, int grid, int block, size_t ldsBytes,
-                                    hipStream_t stream);
-extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int groupCounters, uint64_t seed,
-                                          size_t ldsBytes, hipStream_t stream);
-extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int groupCounters, uint64_t first,
-                                      uint64_t count, uint64_t seed, int initial, int grid, size_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int taskBase, int numTaskRecords, int taskCounter, int grid, int block,
+                                    size_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
+                                          uint64_t seed, size_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
+                                      uint64_t first, uint64_t count, uint64_t seed, int initial, int grid, size_t ldsBytes,
+                                      hipStream_t stream);
 extern "C" hipError_t pmcLaunchTrace(int slot, int gridKind, const double r[3], const double k[3], int32_t* m, double* ds,
                                      int32_t cap, int32_t* n, size_t ldsBytes, hipStream_t stream);
 
@@ -313,9 +314,11 @@ namespace
         double** tdbl[] = {&K.rx, &K.ry, &K.rz, &K.kx, &K.ky, &K.kz, &K.ikx, &K.iky, &K.ikz, &K.s0, &K.ds, &K.target, &K.sext};
         for (double** d : tdbl)
             if ((rc = ctx->allocate<double>(n, d, false, &own))) return rc;
-        int32_t** tints[] = {&K.slot, &K.cell, &K.cijk, &K.launchList};
+        int32_t** tints[] = {&K.cell, &K.cijk};
         for (int32_t** d : tints)
             if ((rc = ctx->allocate<int32_t>(n, d, false, &own))) return rc;
+        // launch lists: per group PMC_LAUNCH_SHARDS regions whose capacities add up to at most group size + 65536
+        if ((rc = ctx->allocate<int32_t>(size_t(n) + size_t(PMC_MAX_GROUPS) * 65536, &K.launchList, false, &own))) return rc;
         if ((rc = ctx->allocate<uint32_t>(n, &K.bits, false, &own))) return rc;
         A.num_slots = n;
         ctx->allocatedSlots = n;
@@ -566,7 +569,12 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     ctx->block = 256;
     int perCU = pmcWalkBlocksPerCU(D.grid_kind, ctx->block, ctx->walkLds);
     if (perCU < 1) perCU = 1;
-    if (const char* env = getenv("PMC_WALK_BLOCKS_PER_CU")) perCU = std::max(1, std::min(perCU, atoi(env)));  // tuning aid
+    // The walk kernel's throughput does not grow beyond two waves per SIMD (it is bound by instruction issue, see
+    // DESIGN.md), and a small footprint leaves room for the transition / launch kernels of the other slot group to
+    // run on the same CUs at the same time.
+    int wantPerCU = 2;
+    if (const char* env = getenv("PMC_WALK_BLOCKS_PER_CU")) wantPerCU = std::max(1, atoi(env));  // tuning aid
+    perCU = std::min(perCU, wantPerCU);
     ctx->grid = ctx->numCU * perCU;
 
     // ---- packet slots
@@ -578,6 +586,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     if ((rc = ctx->allocate<double>(ctx->frameSize, &ctx->frames, true))) return bail(rc);
     D.frames = ctx->frames;
     if ((rc = ctx->allocate<unsigned long long>(PMC_NUM_COUNTERS, &D.counters, true))) return bail(rc);
+    if ((rc = ctx->allocate<unsigned int>(PMC_MAX_GROUPS * PMC_LAUNCH_SHARDS, &D.launch_count, true))) return bail(rc);
     *out = ctx;
     return PMC_OK;
 }
@@ -665,29 +674,32 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_HISTORY, 0, sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(0), 0, 4 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(ctx->evStart, st));
-    const int launchGrid = std::max(1, ctx->numCU * 4);
+    const int launchGrid = std::max(1, ctx->numCU * 4) / PMC_LAUNCH_SHARDS * PMC_LAUNCH_SHARDS + PMC_LAUNCH_SHARDS;
     auto enqueue = [&](int g, bool initial) -> int {
         hipStream_t sg = ctx->groupStream[g];
-        const int gc = PMC_CTR_TASK(g);
+        // the group's launch list: shard regions of shardCap entries from listBase
+        const int numBlocks = (size[g] + PMC_TRANSITION_ALIGN - 1) / PMC_TRANSITION_ALIGN;
+        const int shardCap = (numBlocks + PMC_LAUNCH_SHARDS - 1) / PMC_LAUNCH_SHARDS * PMC_TRANSITION_ALIGN;
+        const int listBase = base[g] + g * 65536;
         if (!initial)
         {
-            HIP_TRY(hipMemsetAsync(ctr + gc, 0, sizeof(unsigned long long), sg));  // task cursor
+            HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(g), 0, sizeof(unsigned long long), sg));  // task cursor
             HIP_TRY(hipEventRecord(ctx->evA[g], sg));
-            HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, base[g], gc, ctx->grid, ctx->block, ctx->walkLds, sg));
+            HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, base[g], size[g], PMC_CTR_TASK(g), ctx->grid, ctx->block, ctx->walkLds, sg));
             haveWalk[g] = true;
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
-            // the lists of the next generation: number of tasks, ended histories, live slots
-            HIP_TRY(hipMemsetAsync(ctr + gc + 1, 0, 3 * sizeof(unsigned long long), sg));
-            HIP_TRY(pmcLaunchTransition(ctx->slot, D.grid_kind, base[g], size[g], gc, seed, ctx->transitionLds, sg));
-            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], gc, first, count, seed, 0, launchGrid,
+            HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_LIVE(g), 0, sizeof(unsigned long long), sg));
+            HIP_TRY(hipMemsetAsync(D.launch_count + g * PMC_LAUNCH_SHARDS, 0, PMC_LAUNCH_SHARDS * sizeof(unsigned int), sg));
+            HIP_TRY(pmcLaunchTransition(ctx->slot, D.grid_kind, base[g], size[g], g, listBase, shardCap, seed, ctx->transitionLds, sg));
+            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], g, listBase, shardCap, first, count, seed, 0, launchGrid,
                                     ctx->transitionLds, sg));
         }
         else
         {
             if (g > 0) HIP_TRY(hipStreamWaitEvent(sg, ctx->evStart, 0));
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
-            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], gc, first, count, seed, 1, (size[g] + 255) / 256,
-                                    ctx->transitionLds, sg));
+            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], g, listBase, shardCap, first, count, seed, 1,
+                                    (size[g] + 255) / 256, ctx->transitionLds, sg));
         }
         HIP_TRY(hipEventRecord(ctx->evC[g], sg));
         HIP_TRY(hipMemcpyAsync(ctx->pinned + g, ctr + PMC_CTR_LIVE(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
@@ -795,10 +807,12 @@ int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out)
     out->stat_overflows = host[5];
     out->rewalk_visits = host[6];
     if (getenv("PMC_PROFILE_DUMP"))
-        fprintf(stderr,
-                "PMC_PROFILE transition: cycles peel %llu pass1 %llu pass2 %llu launch %llu epilogue %llu | lanes peel %llu pass1 %llu "
-                "pass2 %llu launch %llu | waves %llu\n",
-                host[16], host[17], host[18], host[19], host[20], host[21], host[22], host[23], host[24], host[25]);
+    {
+        fprintf(stderr, "PMC_PROFILE transition (wave cycles): stage %llu sort %llu peel %llu pass1 %llu pass2 %llu start %llu append %llu flush %llu\n",
+                host[40], host[41], host[42], host[43], host[44], host[45], host[46], host[47]);
+        fprintf(stderr, "PMC_PROFILE launch (wave cycles): stage %llu list %llu stats %llu launch %llu start %llu append %llu flush %llu\n",
+                host[48], host[49], host[50], host[51], host[52], host[53], host[54]);
+    }
     if (getenv("PMC_PROFILE_DUMP"))
         fprintf(stderr,
                 "PMC_PROFILE walk: service_cycles %llu step_cycles %llu services %llu wave_steps %llu lane_steps %llu slow_lanes %llu\n",

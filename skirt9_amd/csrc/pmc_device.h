@@ -102,9 +102,9 @@ struct SlotArrays
 };
 
 // Walk tasks: the transition and launch kernels start every walk (PathSegmentGenerator::moveInside, location of the
-// first cell, first exit distance) and append its start state here, compacted per slot group: task t of group g lives
-// at index group_base + t of every array.  The walk kernel loads a start state with independent loads (one memory
-// round trip) and never touches the slot arrays except to write the result of the walk.
+// first cell, first exit distance) and leave its start state in the task record of the slot (index = slot; bits ==
+// PMC_TASK_NONE: no walk).  The walk kernel loads a start state with independent loads (one memory round trip) and
+// touches the slot arrays only to write the result of the walk.
 struct TaskArrays
 {
     double* rx; double* ry; double* rz;     // position inside the grid (after moveInside)
@@ -114,12 +114,14 @@ struct TaskArrays
     double* ds;                             // exit distance of the first cell
     double* target;                         // the walk stops in the first segment with tau > target
     double* sext;                           // extinction cross section at the packet's wavelength
-    int32_t* slot;                          // slot that receives the result
     int32_t* cell;                          // first cell
     uint32_t* bits;                         // mode (bits 0-1) | exit axis (2-3) | direction signs (4-6) | size exponent (8-11)
     int32_t* cijk;                          // Cartesian only: cell indices i | j << 10 | k << 20
-    int32_t* launchList;                    // slots whose history has ended (consumed by the launch kernel)
+    int32_t* launchList;                    // slots whose history has ended (consumed by the launch kernel): per slot group
+                                            // PMC_LAUNCH_SHARDS regions of shard_cap entries, counted by DevScene::launch_count
 };
+#define PMC_TASK_NONE 0xFFFFFFFFu
+#define PMC_LAUNCH_SHARDS 64
 
 struct DevScene
 {
@@ -180,6 +182,7 @@ struct DevScene
     double* frames;
     unsigned long long* counters;  // [PMC_NUM_COUNTERS]: [0..6] pmc_counter_values, [8] next history offset,
                                    // [11..31] profiling, [32 + 4 g ..] work counters of slot group g (PMC_CTR_*)
+    unsigned int* launch_count;    // [PMC_MAX_GROUPS][PMC_LAUNCH_SHARDS] entries in the shards of the launch lists
     SlotArrays slots;
     TaskArrays tasks;
     // ---- LDS carve-up (in doubles from the start of dynamic LDS; no kernel has static LDS, so that the octree
@@ -192,10 +195,8 @@ struct DevScene
 
 #define PMC_NUM_COUNTERS 64
 #define PMC_CTR_HISTORY 8
-// per slot group g: cursor of the walk kernel over the task list, number of tasks, number of ended histories, live slots
+// per slot group g: cursor of the walk kernel over the task records, live slots
 #define PMC_CTR_TASK(g) (32 + 4 * (g))
-#define PMC_CTR_NTASKS(g) (33 + 4 * (g))
-#define PMC_CTR_NLAUNCH(g) (34 + 4 * (g))
 #define PMC_CTR_LIVE(g) (35 + 4 * (g))
 #define PMC_MAX_GROUPS 4
 #define PMC_TRANSITION_ALIGN 1024  // slot groups start at multiples of the transition kernel's workgroup size

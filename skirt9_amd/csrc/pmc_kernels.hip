@@ -168,43 +168,46 @@ extern "C" int pmcWalkBlocksPerCU(int gridKind, int block, size_t ldsBytes)
     return e == hipSuccess ? n : 0;
 }
 
-// walks of the task list of one slot group: taskBase = first index of the group's tasks in the task arrays,
-// taskCounter = index of the group's (zeroed) task cursor, followed by its task count
-extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int taskBase, int taskCounter, int grid, int block, size_t ldsBytes,
-                                    hipStream_t stream)
+// walks of the task records [taskBase, taskBase + numTaskRecords) of one slot group; taskCounter = index of the
+// group's (zeroed) cursor
+extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int taskBase, int numTaskRecords, int taskCounter, int grid, int block,
+                                    size_t ldsBytes, hipStream_t stream)
 {
     if (gridKind == PMC_GRID_OCTREE)
-        hipLaunchKernelGGL(walkKernel<GRID_TREE>, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, taskCounter);
+        hipLaunchKernelGGL(walkKernel<GRID_TREE>, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter);
     else
-        hipLaunchKernelGGL(walkKernel<GRID_CART>, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, taskCounter);
+        hipLaunchKernelGGL(walkKernel<GRID_CART>, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter);
     return hipGetLastError();
 }
 
-// transitions of the slots in [slotBase, slotBase + numSlots); groupCounters = PMC_CTR_TASK(group)
-extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int groupCounters, uint64_t seed,
-                                          size_t ldsBytes, hipStream_t stream)
+// transitions of the slots [slotBase, slotBase + numSlots) of slot group `group`; ended histories go to the group's
+// sharded launch list at listBase (shardCap entries per shard)
+extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
+                                          uint64_t seed, size_t ldsBytes, hipStream_t stream)
 {
     const int block = PMC_TRANSITION_BLOCK;
     const int grid = (numSlots + block - 1) / block;
     if (gridKind == PMC_GRID_OCTREE)
-        hipLaunchKernelGGL(transitionKernel<GRID_TREE>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots,
-                           groupCounters, seed);
+        hipLaunchKernelGGL(transitionKernel<GRID_TREE>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group,
+                           listBase, shardCap, seed);
     else
-        hipLaunchKernelGGL(transitionKernel<GRID_CART>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots,
-                           groupCounters, seed);
+        hipLaunchKernelGGL(transitionKernel<GRID_CART>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group,
+                           listBase, shardCap, seed);
     return hipGetLastError();
 }
 
-// launches of new histories into the slots whose history ended (initial: into all slots of the group)
-extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int groupCounters, uint64_t first,
-                                      uint64_t count, uint64_t seed, int initial, int grid, size_t ldsBytes, hipStream_t stream)
+// launches of new histories into the slots whose history ended (initial: into all slots of the group); grid must be a
+// multiple of PMC_LAUNCH_SHARDS unless initial
+extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
+                                      uint64_t first, uint64_t count, uint64_t seed, int initial, int grid, size_t ldsBytes,
+                                      hipStream_t stream)
 {
     if (gridKind == PMC_GRID_OCTREE)
-        hipLaunchKernelGGL(launchKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, groupCounters,
-                           first, count, seed, initial);
+        hipLaunchKernelGGL(launchKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, listBase,
+                           shardCap, first, count, seed, initial);
     else
-        hipLaunchKernelGGL(launchKernel<GRID_CART>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, groupCounters,
-                           first, count, seed, initial);
+        hipLaunchKernelGGL(launchKernel<GRID_CART>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, listBase,
+                           shardCap, first, count, seed, initial);
     return hipGetLastError();
 }
 
