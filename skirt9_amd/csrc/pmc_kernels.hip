@@ -57,7 +57,8 @@
     #define PMC_WALK_STEPS 2  // steps between two service checks
 #endif
 #ifndef PMC_TRANSITION_BLOCK
-    #define PMC_TRANSITION_BLOCK 1024  // lanes per workgroup of the transition kernel (regrouped by event type)
+    #define PMC_TRANSITION_BLOCK 512  // lanes per workgroup of the transition kernel (regrouped by event type); small
+                                      // enough to share a CU with the walk kernel of the other slot group
 #endif
 #define PMC_TASK_CHUNK 128   // slots a wave takes from the global cursor at a time
 
