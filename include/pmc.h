@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 1
+#define PMC_ABI_VERSION 2
 
 enum { PMC_OK = 0, PMC_ERR_INVALID = -1, PMC_ERR_UNSUPPORTED = -2, PMC_ERR_DEVICE = -3, PMC_ERR_NOMEM = -4 };
 
@@ -103,6 +103,7 @@ typedef struct pmc_options
 enum { PMC_SOURCE_POINT = 1, PMC_SOURCE_SERSIC = 2, PMC_SOURCE_UNIFORM_BOX = 3 };
 enum { PMC_LAMBDA_OLIGO = 1, PMC_LAMBDA_TABULATED = 2 };
 enum { PMC_BIAS_NONE = 0, PMC_BIAS_LOG = 1, PMC_BIAS_LIN = 2 };
+enum { PMC_SED_TABULATED = 0, PMC_SED_BLACKBODY = 1 };
 
 typedef struct pmc_source
 {
@@ -130,6 +131,11 @@ typedef struct pmc_source
     const double* sed_P;
     int32_t       bias_kind;        /* PMC_BIAS_*: LogWavelengthDistribution / LinWavelengthDistribution */
     double        bias_min, bias_max;
+    /* SED::specificLuminosity for the bias weight (NormalizedSource.cpp:91-105).  PMC_SED_TABULATED: log-log
+       interpolation of (sed_lambda, sed_p).  PMC_SED_BLACKBODY: f2 / lambda^5 / (exp(f1 / lambda) - 1) / ltot
+       (BlackBodySED.cpp:36-39, PlanckFunction.cpp:24-27) */
+    int32_t       sed_kind;         /* PMC_SED_* */
+    double        sed_f1, sed_f2, sed_ltot;
 } pmc_source;
 
 /* ---------------------------------------------------------------- instruments ---- */

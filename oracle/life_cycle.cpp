@@ -550,9 +550,12 @@ namespace
                         lambda = s.bias_min + (s.bias_max - s.bias_min) * rng.uniform();
                     else
                         lambda = exp(logMin + logWidth * rng.uniform());
-                    // specific luminosity of the tabulated SED: log-log interpolation of the normalised table
+                    // SED::specificLuminosity: analytic for a black body (BlackBodySED.cpp:36-39, PlanckFunction.cpp:24-27),
+                    // otherwise log-log interpolation of the normalised table
                     double sl = 0.;
-                    if (lambda >= s.sed_lambda[0] && lambda <= s.sed_lambda[s.num_sed - 1])
+                    if (s.sed_kind == PMC_SED_BLACKBODY)
+                        sl = s.sed_f2 / pow(lambda, 5) / (exp(s.sed_f1 / lambda) - 1.0) / s.sed_ltot;
+                    else if (lambda >= s.sed_lambda[0] && lambda <= s.sed_lambda[s.num_sed - 1])
                     {
                         int i = locate(s.sed_lambda, s.num_sed, lambda);
                         if (i < 0) i = 0;

@@ -487,6 +487,10 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     D.bias_kind = src.bias_kind;
     D.bias_min = src.bias_min;
     D.bias_max = src.bias_max;
+    D.sed_kind = src.sed_kind;
+    D.sed_f1 = src.sed_f1;
+    D.sed_f2 = src.sed_f2;
+    D.sed_ltot = src.sed_ltot;
     D.lds_src_off = transDoubles;
     if (src.kind == PMC_SOURCE_SERSIC)
     {

@@ -174,6 +174,8 @@ struct DevScene
     const double* sed_P;
     int32_t bias_kind;
     double  bias_min, bias_max;
+    int32_t sed_kind;
+    double  sed_f1, sed_f2, sed_ltot;
     // ---- instruments
     int32_t num_instruments;
     DevInstrument inst[PMC_MAX_INSTRUMENTS];

@@ -539,6 +539,10 @@ namespace skh
             _scene.source.sed_lambda = _sedLambda.data();
             _scene.source.sed_p = _sedp.data();
             _scene.source.sed_P = _sedP.data();
+            _scene.source.sed_kind = PMC_SED_BLACKBODY;
+            _scene.source.sed_f1 = f1;
+            _scene.source.sed_f2 = f2;
+            _scene.source.sed_ltot = Ltot;
             // bias distribution range: Default = source range; Log/Lin = configured range intersected with source range
             double lo = sourceMin, hi = sourceMax;
             if (_source.biasDistType != "DefaultWavelengthDistribution")

@@ -22,14 +22,16 @@ def _same_file(path_a, path_b):
     return a == b
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg2small"])
-def test_byte_identical_to_reference(name, tmp_path):
+@pytest.mark.parametrize("name,nfiles", [("cfg1", 11), ("cfg2small", 11), ("cfg3small", 27)])
+def test_byte_identical_to_reference(name, nfiles, tmp_path):
+    """cfg3small: panchromatic sampling with a wavelength bias, tabulated dust, 20 wavelength bins, and three
+    instruments (scattering levels, a FrameInstrument sharing its observer, a second observer)"""
     sim = Simulation(ski(name + ".ski")).setup()
     frames, counters = O.run_primary(sim, 0, sim.num_packets, O.RNG_MT19937)
     assert counters.histories == sim.num_packets
     sim.write(frames, str(tmp_path))
-    expected = sorted(f for f in os.listdir(golden("")) if f.startswith(name + "_i0_"))
-    assert len(expected) == 11
+    expected = sorted(f for f in os.listdir(golden("")) if f.startswith(name + "_i") and (f.endswith(".fits") or f.endswith(".dat")))
+    assert len(expected) == nfiles
     for f in expected:
         assert os.path.exists(tmp_path / f), f
         assert _same_file(golden(f), str(tmp_path / f)), f"{f} differs from the reference output"
