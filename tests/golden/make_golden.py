@@ -8,7 +8,8 @@
 Fixtures:
   cfg1_*       config 1 (tests/ski/cfg1.ski): 10^6 packets, seed 0, one thread -> FITS/SED/statistics files
   cfg2small_*  reduced config 2 (tests/ski/cfg2small.ski): 2x10^4 packets -> FITS/SED/statistics files
-  cfg3small_*  reduced config 3 (tests/ski/cfg3small.ski): panchromatic, three instruments, 2x10^4 packets -> files
+  cfg3small_*  reduced config 3 (tests/ski/cfg3small.ski): panchromatic, four instruments, 2x10^4 packets -> files
+  cfg1nf_*     non-forced scattering variant of config 1 (tests/ski/cfg1nf.ski): 2x10^5 packets -> files
   *_rays.txt / *_rays_ref.txt   fixed rays and the reference's (m, ds) sequences (C99 hex floats)
   *_cells.npz  per-cell volume and number density as the reference computed them (bit patterns), and the dust
                cross sections at 0.55 micron
@@ -45,7 +46,7 @@ def rays(scale, n, seed):
 def main():
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
-    for name, scale in (("cfg1", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg3small", None)):
+    for name, scale in (("cfg1", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg3small", None), ("cfg1nf", None)):
         ski = os.path.join(ROOT, "tests", "ski", name + ".ski")
         with tempfile.TemporaryDirectory() as tmp:
             subprocess.check_call([REF, "run", ski, "-t", "1", "-o", tmp], cwd=tmp, stdout=subprocess.DEVNULL)
@@ -53,7 +54,7 @@ def main():
                 if f.endswith(".fits") or f.endswith(".dat"):
                     shutil.copy(os.path.join(tmp, f), os.path.join(HERE, f))
             if scale is None:
-                continue  # same grid as cfg2small: no separate ray / cell fixtures
+                continue  # grids of the same kinds as above: no separate ray / cell fixtures
             # rays: directions are written as hex floats so that both sides parse identical doubles
             rayfile = os.path.join(HERE, name + "_rays.txt")
             with open(rayfile, "w") as fh:

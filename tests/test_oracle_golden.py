@@ -22,10 +22,11 @@ def _same_file(path_a, path_b):
     return a == b
 
 
-@pytest.mark.parametrize("name,nfiles", [("cfg1", 11), ("cfg2small", 11), ("cfg3small", 27)])
+@pytest.mark.parametrize("name,nfiles", [("cfg1", 11), ("cfg2small", 11), ("cfg3small", 27), ("cfg1nf", 12)])
 def test_byte_identical_to_reference(name, nfiles, tmp_path):
     """cfg3small: panchromatic sampling with a wavelength bias, tabulated dust, 20 wavelength bins, and three
-    instruments (scattering levels, a FrameInstrument sharing its observer, a second observer)"""
+    instruments (scattering levels, a FrameInstrument sharing its observer, a second observer); cfg1nf: non-forced
+    scattering, box source that sticks out of the grid, isotropic and strongly forward scattering dust"""
     sim = Simulation(ski(name + ".ski")).setup()
     frames, counters = O.run_primary(sim, 0, sim.num_packets, O.RNG_MT19937)
     assert counters.histories == sim.num_packets
