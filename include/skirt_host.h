@@ -31,6 +31,9 @@ const pmc_scene* skh_scene(const skh_simulation* sim);
 uint64_t skh_num_packets(const skh_simulation* sim);
 int32_t  skh_seed(const skh_simulation* sim);
 uint64_t skh_setup_draws(const skh_simulation* sim);
+/* luminosity that one launched packet carries at oligochromatic wavelength `index` (SourceSystem.cpp:96,105-106 times the
+   weight of NormalizedSource.cpp:91-105); negative if the simulation is not oligochromatic or the index is out of range */
+double   skh_packet_luminosity(const skh_simulation* sim, int32_t index);
 int64_t  skh_frame_size(const skh_simulation* sim);
 int skh_frame_layout(const skh_simulation* sim, int32_t instrument, pmc_frame_layout* out);
 /* calibrates `frames` in place and writes <prefix>_<instrument>_*.fits / _sed.dat / _sedstats.dat into outdir */

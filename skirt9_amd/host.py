@@ -52,6 +52,8 @@ def lib():
         L.skh_num_packets.argtypes = [C.c_void_p]
         L.skh_seed.restype = C.c_int32
         L.skh_seed.argtypes = [C.c_void_p]
+        L.skh_packet_luminosity.restype = C.c_double
+        L.skh_packet_luminosity.argtypes = [C.c_void_p, C.c_int32]
         L.skh_setup_draws.restype = C.c_uint64
         L.skh_setup_draws.argtypes = [C.c_void_p]
         L.skh_frame_size.restype = C.c_int64
@@ -108,6 +110,13 @@ class Simulation:
     @property
     def seed(self):
         return int(lib().skh_seed(self._h))
+
+    def packet_luminosity(self, index=0):
+        """luminosity carried by one launched packet at oligochromatic wavelength `index`"""
+        value = float(lib().skh_packet_luminosity(self._h, index))
+        if value < 0:
+            raise ValueError("not an oligochromatic simulation, or wavelength index out of range")
+        return value
 
     @property
     def setup_draws(self):

@@ -113,6 +113,13 @@ int32_t skh_seed(const skh_simulation* h)
     return h->sim->seed();
 }
 
+double skh_packet_luminosity(const skh_simulation* h, int32_t index)
+{
+    const pmc_source& src = h->sim->scene().source;
+    if (src.lambda_mode != PMC_LAMBDA_OLIGO || index < 0 || index >= src.num_oligo) return -1.;
+    return src.packet_luminosity * src.oligo_weight[index];
+}
+
 uint64_t skh_setup_draws(const skh_simulation* h)
 {
     return h->sim->setupDraws();
