@@ -26,7 +26,7 @@ extern "C" int pmcWalkBlocksPerCU(int gridKind, int block, size_t ldsBytes);
 extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int taskBase, int numTaskRecords, int taskCounter, int grid, int block,
                                     size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
-                                          uint64_t seed, size_t ldsBytes, hipStream_t stream);
+                                          uint64_t seed, int maxBlocks, size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
                                       uint64_t first, uint64_t count, uint64_t seed, int initial, int grid, size_t ldsBytes,
                                       hipStream_t stream);
@@ -679,6 +679,10 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(0), 0, 4 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(ctx->evStart, st));
     const int launchGrid = std::max(1, ctx->numCU * 4) / PMC_LAUNCH_SHARDS * PMC_LAUNCH_SHARDS + PMC_LAUNCH_SHARDS;
+    int transitionBlocks = ctx->numCU * 4;  // persistent transition workgroups (tables staged once per workgroup)
+    if (const char* env = getenv("PMC_TRANSITION_BLOCKS_PER_CU")) transitionBlocks = ctx->numCU * std::max(1, atoi(env));
+    // (a multiple of the shard count, so that tile t always appends to launch-list shard t mod shards)
+    transitionBlocks = (transitionBlocks + PMC_LAUNCH_SHARDS - 1) / PMC_LAUNCH_SHARDS * PMC_LAUNCH_SHARDS;
     auto enqueue = [&](int g, bool initial) -> int {
         hipStream_t sg = ctx->groupStream[g];
         // the group's launch list: shard regions of shardCap entries from listBase
@@ -694,7 +698,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_LIVE(g), 0, sizeof(unsigned long long), sg));
             HIP_TRY(hipMemsetAsync(D.launch_count + g * PMC_LAUNCH_SHARDS, 0, PMC_LAUNCH_SHARDS * sizeof(unsigned int), sg));
-            HIP_TRY(pmcLaunchTransition(ctx->slot, D.grid_kind, base[g], size[g], g, listBase, shardCap, seed, ctx->transitionLds, sg));
+            HIP_TRY(pmcLaunchTransition(ctx->slot, D.grid_kind, base[g], size[g], g, listBase, shardCap, seed, transitionBlocks,
+                                        ctx->transitionLds, sg));
             HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], g, listBase, shardCap, first, count, seed, 0, launchGrid,
                                     ctx->transitionLds, sg));
         }
@@ -810,6 +815,7 @@ int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out)
     out->scatterings = host[4];
     out->stat_overflows = host[5];
     out->rewalk_visits = host[6];
+    if (getenv("PMC_DEBUG_DUMP")) fprintf(stderr, "PMC_DEBUG flush: short %llu long %llu short_ell_neg %llu\n", host[60], host[61], host[62]);
     if (getenv("PMC_PROFILE_DUMP"))
     {
         fprintf(stderr, "PMC_PROFILE transition (wave cycles): stage %llu sort %llu peel %llu pass1 %llu pass2 %llu start %llu append %llu flush %llu\n",
@@ -821,6 +827,9 @@ int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out)
         fprintf(stderr,
                 "PMC_PROFILE walk: service_cycles %llu step_cycles %llu services %llu wave_steps %llu lane_steps %llu slow_lanes %llu\n",
                 host[11], host[12], host[13], host[14], host[15], host[26]);
+    if (getenv("PMC_PROFILE_DUMP"))
+        fprintf(stderr, "PMC_PROFILE walk tail (after the task list is exhausted): wave_steps %llu lane_steps %llu wave_cycles %llu max_wave_cycles(last launch accumulates) %llu\n",
+                host[56], host[57], host[58], host[59]);
     if (getenv("PMC_PROFILE_DUMP"))
         fprintf(stderr, "PMC_PROFILE walk step phases (lane-0 cycles): pre-link %llu link-wait %llu descend %llu head-wait %llu enter %llu\n",
                 host[27], host[28], host[29], host[30], host[31]);

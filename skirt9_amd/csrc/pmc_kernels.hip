@@ -49,6 +49,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <math.h>
+#include <algorithm>
 
 #ifndef PMC_WALK_REFILL
     #define PMC_WALK_REFILL 12  // waiting (idle or pending) lanes in a wave that trigger a service round
@@ -184,10 +185,10 @@ extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int taskBase, int nu
 // transitions of the slots [slotBase, slotBase + numSlots) of slot group `group`; ended histories go to the group's
 // sharded launch list at listBase (shardCap entries per shard)
 extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
-                                          uint64_t seed, size_t ldsBytes, hipStream_t stream)
+                                          uint64_t seed, int maxBlocks, size_t ldsBytes, hipStream_t stream)
 {
     const int block = PMC_TRANSITION_BLOCK;
-    const int grid = (numSlots + block - 1) / block;
+    const int grid = std::max(1, std::min((numSlots + block - 1) / block, maxBlocks));
     if (gridKind == PMC_GRID_OCTREE)
         hipLaunchKernelGGL(transitionKernel<GRID_TREE>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group,
                            listBase, shardCap, seed);
