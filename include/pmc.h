@@ -228,7 +228,8 @@ int pmc_download(pmc_ctx* ctx, double* host_frames, int64_t num_doubles);
 double* pmc_frames_device(pmc_ctx* ctx);
 int64_t pmc_frames_size(pmc_ctx* ctx);
 /* milliseconds spent in the walk kernel (the dominant kernel) during the most recent pmc_run_primary, summed over
-   its launches and measured with HIP events on the context's stream */
+   its launches and measured with HIP events on the streams they run on (the launches of different slot groups
+   overlap, so the sum can exceed the segment time reported by pmc_last_timing) */
 int pmc_last_kernel_ms(pmc_ctx* ctx, float* ms);
 int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out);
 int pmc_reset_counters(pmc_ctx* ctx);
@@ -237,10 +238,12 @@ int pmc_reset_counters(pmc_ctx* ctx);
 int pmc_trace_ray(pmc_ctx* ctx, const double r[3], const double k[3], int32_t* m, double* ds, int32_t cap, int32_t* n);
 /* tuning knobs (0 = default): threads per workgroup and workgroups of the persistent walk kernel */
 int pmc_set_launch(pmc_ctx* ctx, int32_t block, int32_t grid);
-/* number of photon histories kept in flight on the device (default 4 Mi; environment PMC_NUM_SLOTS) */
+/* number of photon histories kept in flight on the device (default 4 Mi; environment PMC_NUM_SLOTS).  The slots are
+   divided into slot groups (default 2; environment PMC_NUM_GROUPS) whose generations run on separate streams */
 int pmc_set_num_slots(pmc_ctx* ctx, int64_t num_slots);
 /* HIP-event timing of the most recent pmc_run_primary: whole segment, sum over its walk-kernel launches, sum over
-   its transition-kernel launches, and the number of generations (walk + transition launch pairs) */
+   its transition + launch kernel launches, and the number of generations (walk, transition, launch kernel triples,
+   counted over all slot groups) */
 int pmc_last_timing(pmc_ctx* ctx, float* total_ms, float* walk_ms, float* transition_ms, int32_t* generations);
 
 #ifdef __cplusplus
