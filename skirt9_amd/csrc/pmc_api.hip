@@ -23,8 +23,8 @@
 extern "C" hipError_t pmcUploadScene(int slot, const DevScene* scene, hipStream_t stream);
 extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds);
 extern "C" int pmcWalkBlocksPerCU(int gridKind, int block, size_t ldsBytes);
-extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int taskBase, int numTaskRecords, int taskCounter, int grid, int block,
-                                    size_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int taskBase, int numTaskRecords, int taskCounter, uint64_t seed, int grid,
+                                    int block, size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
                                           uint64_t seed, int maxBlocks, size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
@@ -693,7 +693,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         {
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(g), 0, sizeof(unsigned long long), sg));  // task cursor
             HIP_TRY(hipEventRecord(ctx->evA[g], sg));
-            HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, base[g], size[g], PMC_CTR_TASK(g), ctx->grid, ctx->block, ctx->walkLds, sg));
+            HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, base[g], size[g], PMC_CTR_TASK(g), seed, ctx->grid, ctx->block, ctx->walkLds,
+                                  sg));
             haveWalk[g] = true;
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_LIVE(g), 0, sizeof(unsigned long long), sg));

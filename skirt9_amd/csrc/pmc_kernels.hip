@@ -93,6 +93,32 @@ namespace
         return pmc_bits_to_unit(c[0], c[1]);
     }
 
+    // Random::exponCutoff (Random.cpp:105-116)
+    __device__ __forceinline__ double exponCutoff(Rng& rng, uint64_t seed, double xmax)
+    {
+        if (xmax == 0.0) return 0.0;
+        if (xmax < 1e-10) return rngUniform(rng, seed) * xmax;
+        double x = -log(1.0 - rngUniform(rng, seed) * (1.0 - exp(-xmax)));
+        while (x > xmax) x = -log(1.0 - rngUniform(rng, seed) * (1.0 - exp(-xmax)));
+        return x;
+    }
+
+    __device__ __forceinline__ void loadRng(const SlotArrays& A, int slot, Rng& rng)
+    {
+        const uint64_t h = A.history[slot];
+        const uint32_t rb = A.rngBlock[slot];
+        rng.h0 = (uint32_t)h;
+        rng.h1 = (uint32_t)(h >> 32);
+        rng.block = rb >> 1;
+        rng.have = rb & 1;
+        rng.spare = A.rngSpare[slot];
+    }
+    __device__ __forceinline__ void storeRng(const SlotArrays& A, int slot, const Rng& rng)
+    {
+        A.rngBlock[slot] = (rng.block << 1) | (rng.have & 1);
+        A.rngSpare[slot] = rng.spare;
+    }
+
     __device__ __forceinline__ int locateBasic(const double* xv, double x, int n)
     {
         int jl = -1, ju = n;
@@ -172,13 +198,15 @@ extern "C" int pmcWalkBlocksPerCU(int gridKind, int block, size_t ldsBytes)
 
 // walks of the task records [taskBase, taskBase + numTaskRecords) of one slot group; taskCounter = index of the
 // group's (zeroed) cursor
-extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int taskBase, int numTaskRecords, int taskCounter, int grid, int block,
-                                    size_t ldsBytes, hipStream_t stream)
+extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int taskBase, int numTaskRecords, int taskCounter, uint64_t seed, int grid,
+                                    int block, size_t ldsBytes, hipStream_t stream)
 {
     if (gridKind == PMC_GRID_OCTREE)
-        hipLaunchKernelGGL(walkKernel<GRID_TREE>, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter);
+        hipLaunchKernelGGL(walkKernel<GRID_TREE>, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter,
+                           seed);
     else
-        hipLaunchKernelGGL(walkKernel<GRID_CART>, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter);
+        hipLaunchKernelGGL(walkKernel<GRID_CART>, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter,
+                           seed);
     return hipGetLastError();
 }
 
