@@ -292,8 +292,8 @@ namespace
         std::memset(&A, 0, sizeof(A));
         auto& own = ctx->slotAllocations;
         int rc;
-        double** dbl[] = {&A.rx, &A.ry, &A.rz, &A.kx, &A.ky, &A.kz, &A.lambda, &A.W, &A.Lthreshold, &A.pW, &A.target,
-                          &A.taupath, &A.rngSpare, &A.tau, &A.sint, &A.nint};
+        double** dbl[] = {&A.rx, &A.ry, &A.rz, &A.kx, &A.ky, &A.kz, &A.lambda, &A.W, &A.Lthreshold, &A.taupath, &A.rngSpare, &A.sint,
+                          &A.nint};
         for (double** d : dbl)
             if ((rc = ctx->allocate<double>(n, d, false, &own))) return rc;
         if ((rc = ctx->allocate<uint64_t>(n, &A.history, false, &own))) return rc;
@@ -301,6 +301,8 @@ namespace
         int32_t** ints[] = {&A.dustIndex, &A.mode, &A.nscatt, &A.pscatt, &A.cellhint, &A.mint};
         for (int32_t** d : ints)
             if ((rc = ctx->allocate<int32_t>(n, d, true, &own))) return rc;
+        if ((rc = ctx->allocate<double>(size_t(n) * PMC_MAX_INSTRUMENTS, &A.ppW, false, &own))) return rc;
+        if ((rc = ctx->allocate<double>(size_t(n) * PMC_MAX_INSTRUMENTS, &A.ptau, false, &own))) return rc;
         if ((rc = ctx->allocate<int32_t>(size_t(n) * PMC_MAX_INSTRUMENTS, &A.ell, true, &own))) return rc;
         if ((rc = ctx->allocate<int32_t>(size_t(n) * PMC_MAX_INSTRUMENTS, &A.nstat, true, &own))) return rc;
         if (ctx->dev.any_stats)
@@ -311,15 +313,17 @@ namespace
         }
         TaskArrays& K = ctx->dev.tasks;
         std::memset(&K, 0, sizeof(K));
+        // task records: the propagation walk + one peel-off walk per instrument, per slot
+        const size_t nt = size_t(n) * size_t(1 + ctx->dev.num_instruments);
         double** tdbl[] = {&K.rx, &K.ry, &K.rz, &K.kx, &K.ky, &K.kz, &K.ikx, &K.iky, &K.ikz, &K.s0, &K.ds, &K.target, &K.sext};
         for (double** d : tdbl)
-            if ((rc = ctx->allocate<double>(n, d, false, &own))) return rc;
+            if ((rc = ctx->allocate<double>(nt, d, false, &own))) return rc;
         int32_t** tints[] = {&K.cell, &K.cijk};
         for (int32_t** d : tints)
-            if ((rc = ctx->allocate<int32_t>(n, d, false, &own))) return rc;
+            if ((rc = ctx->allocate<int32_t>(nt, d, false, &own))) return rc;
         // launch lists: per group PMC_LAUNCH_SHARDS regions whose capacities add up to at most group size + 65536
         if ((rc = ctx->allocate<int32_t>(size_t(n) + size_t(PMC_MAX_GROUPS) * 65536, &K.launchList, false, &own))) return rc;
-        if ((rc = ctx->allocate<uint32_t>(n, &K.bits, false, &own))) return rc;
+        if ((rc = ctx->allocate<uint32_t>(nt, &K.bits, false, &own))) return rc;
         A.num_slots = n;
         ctx->allocatedSlots = n;
         ctx->sceneDirty = true;

@@ -77,34 +77,36 @@ struct SlotArrays
     double* lambda;                         // wavelength
     double* W;                              // weight (luminosity = W / lambda)
     double* Lthreshold;
-    double* pW;                             // weight of the peel-off packet under way
-    double* target;                         // pass 2: sampled optical depth; peel-off: taumax (MediumSystem.cpp:1199)
-    double* taupath;
+    double* ppW;                            // [PMC_MAX_INSTRUMENTS][num_slots] weight of the cycle's peel-off packet towards
+                                            // the observer whose instrument group starts at that instrument
+    double* taupath;                        // optical depth of the whole path (pass 1), kept for the escape weight
     uint64_t* history;
     double*  rngSpare;
     uint32_t* rngBlock;                     // (block << 1) | have
     int32_t* dustIndex;                     // DustMix::indexForLambda(lambda)
-    int32_t* mode;                          // bits 0-1 walk mode, bits 2-4 instrument served by the peel-off, bit 5 alive
+    int32_t* mode;                          // bit 5 alive, bits 8-15 observers (group leaders) with a peel-off packet this cycle
     int32_t* nscatt;
-    int32_t* pscatt;                        // numScatt of the peel-off packet
+    int32_t* pscatt;                        // numScatt of the cycle's peel-off packets (0: emission)
     int32_t* cellhint;                      // octree leaf that contains the position, or -1
     int32_t* ell;                           // [PMC_MAX_INSTRUMENTS][num_slots] wavelength bin per instrument
     int32_t* nstat;                         // [PMC_MAX_INSTRUMENTS][num_slots] length of the contribution list
     // walk results
-    double* tau;                            // cumulative optical depth of the walk (inf: peel-off contribution is zero)
-    double* sint;                           // pass 2: interaction distance
+    double* ptau;                           // [PMC_MAX_INSTRUMENTS][num_slots] optical depth towards that observer (inf: the
+                                            // contribution is zero)
+    double* sint;                           // propagation walk: interaction distance
     double* nint;                           //         density of the interaction cell
-    int32_t* mint;                          //         interaction cell (-1: none)
+    int32_t* mint;                          //         interaction cell (-1: no interaction, the history ends)
     // per-history contribution lists: bin[(inst*CAP + e)*num_slots + slot], w likewise
     int32_t* statBin;
     double*  statW;
     int64_t  num_slots;
 };
 
-// Walk tasks: the transition and launch kernels start every walk (PathSegmentGenerator::moveInside, location of the
-// first cell, first exit distance) and leave its start state in the task record of the slot (index = slot; bits ==
-// PMC_TASK_NONE: no walk).  The walk kernel loads a start state with independent loads (one memory round trip) and
-// touches the slot arrays only to write the result of the walk.
+// Walk tasks: the transition and launch kernels start every walk of a cycle (PathSegmentGenerator::moveInside, location
+// of the first cell, first exit distance) and leave its start state in a task record of the slot: record 0 = the
+// propagation walk, record 1 + g = the peel-off walk towards the observer whose instrument group starts at g; index =
+// record * num_slots + slot; bits == PMC_TASK_NONE: no walk.  The walk kernel runs the records of a slot one after the
+// other in one lane and touches the slot arrays only to write the results.
 struct TaskArrays
 {
     double* rx; double* ry; double* rz;     // position inside the grid (after moveInside)
