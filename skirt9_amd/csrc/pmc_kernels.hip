@@ -52,10 +52,11 @@
 #include <algorithm>
 
 #ifndef PMC_WALK_REFILL
-    #define PMC_WALK_REFILL 12  // waiting (idle or pending) lanes in a wave that trigger a service round
+    #define PMC_WALK_REFILL 40  // waiting (idle or pending) lanes in a wave that trigger a service round (a round costs
+                                // several hundred instructions whatever the number of lanes it serves)
 #endif
 #ifndef PMC_WALK_STEPS
-    #define PMC_WALK_STEPS 2  // steps between two service checks
+    #define PMC_WALK_STEPS 4  // steps between two service checks
 #endif
 #ifndef PMC_TRANSITION_BLOCK
     #define PMC_TRANSITION_BLOCK 512  // lanes per workgroup of the transition kernel (regrouped by event type); small
