@@ -586,7 +586,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     ctx->grid = ctx->numCU * perCU;
 
     // ---- packet slots
-    int64_t slots = 4 * 1024 * 1024;
+    int64_t slots = 8 * 1024 * 1024;  // about 1 KB of state per slot
     if (const char* env = getenv("PMC_NUM_SLOTS")) slots = std::max<int64_t>(1024, atoll(env));
     ctx->numSlots = slots;
 
