@@ -35,6 +35,25 @@ SKI = os.path.join(ROOT, "tests", "ski", "cfg2.ski")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def pmc_traffic(packets_per_step):
+    """HBM bytes the walk kernel moves in one step (all its launches), from the newest committed PMC summary
+    profiles/r*_pmc_hbm.csv: FETCH_SIZE + WRITE_SIZE (KiB, separate rocprofv3 --pmc passes over one step of 2e7
+    packets of this workload; tools/run_profile_set.sh, tools/pmc_hbm_summary.py), scaled by the packet count.  The
+    kernel's reads are 4- and 8-byte gathers (64-byte fabric requests), so the gfx950 x2 correction for wide coalesced
+    reads (MI355X_MICROARCH.md, HBM) does not apply; Infinity-Cache hits are included in the counter."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.csv")),
+                   key=lambda f: [int(x) for x in re.findall(r"[0-9]+", os.path.basename(f))])
+    if not files:
+        return None
+    kib = 0.0
+    for row in csv.DictReader(open(files[-1])):
+        if row["kernel"] == "walkKernel":
+            kib += float(row["sum_KiB_per_step_of_2e7_packets"])
+    return kib * 1024.0 / 2e7 * packets_per_step if kib else None
+
+
 def cpu_baseline(packets_per_core=100000):
     """photon packets/s of the CPU path on this box's host cores, on a bounded sample (about 10-30 s)"""
     cores = min(os.cpu_count() or 1, 24)  # the reference caps a process at 24 threads (ParallelFactory.cpp:43-50)
@@ -75,6 +94,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--packets", type=float, default=1e8, help="photon packets per step and GPU")
     ap.add_argument("--ski", default=SKI)
+    ap.add_argument("--source", choices=["sersic", "uniform"], default="sersic",
+                    help="sersic: cfg2.ski as is (the headline workload); uniform: the same scene with the Sersic source "
+                         "replaced by a UniformBoxGeometry source of +-10 x +-10 x +-1 kpc (north_star's second source)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -100,7 +122,17 @@ def main():
     total_per_step = P * world
     # every rank sets up the same scene (replica of grid, densities, tables); numPackets = packets of one step over
     # all ranks, so that the per-packet luminosity is that of the whole segment
-    sim = Simulation(args.ski, num_packets=total_per_step).setup()
+    ski_path = args.ski
+    if args.source == "uniform":
+        text = open(args.ski).read()
+        new = ('<UniformBoxGeometry minX="-10000 pc" maxX="10000 pc" minY="-10000 pc" maxY="10000 pc" '
+               'minZ="-1000 pc" maxZ="1000 pc"/>')
+        text, nsub = re.subn(r"<SersicGeometry[^>]*/>", new, text, count=1)
+        if nsub != 1:
+            raise SystemExit("--source uniform: no SersicGeometry source in the ski file")
+        ski_path = os.path.join(tempfile.mkdtemp(prefix=f"bench_r{rank}_"), "cfg2u.ski")
+        open(ski_path, "w").write(text)
+    sim = Simulation(ski_path, num_packets=total_per_step).setup()
     eng = Engine(sim.scene, local_rank)
     frames = torch.zeros(sim.frame_size, dtype=torch.float64, device=f"cuda:{local_rank}")
     eng.bind_frames(frames.data_ptr(), frames.numel())
@@ -160,12 +192,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Sersic source, 953688-cell PolicyTreeSpatialGrid octree "
+            "config": {"workload": "BASELINE configs[1]: " + ("Sersic" if args.source == "sersic" else "uniform-box")
+                                   + " source, 953688-cell PolicyTreeSpatialGrid octree "
                                    "(exp-disk dust, tau_z=1), 0.55 micron, forced scattering, peel-off to one "
-                                   "FullInstrument 512^2 (components + statistics), tests/ski/cfg2.ski",
-                       "packets_per_step_per_gpu": P, "cells": 953688, "parallelism": f"history-range x{world}"},
+                                   "FullInstrument 512^2 (components + statistics), " + os.path.relpath(args.ski, ROOT),
+                       "packets_per_step_per_gpu": P, "cells": 953688 if args.ski == SKI else None,
+                       "parallelism": f"history-range x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(P) if args.ski == SKI else None,
                          "kernel": "walkKernel<octree>: all launches of one step, overlapped on the slot groups' streams "
                                    "(denominator: segment_ms)",
                          "kernel_ms": mean_ms, "walk_kernel_ms_sum": walk_ms_sum,
