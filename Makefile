@@ -15,7 +15,7 @@ all: skirt9_amd/lib/libskirthost.so skirt9_amd/lib/libpmc.so skirt9_amd/lib/skir
 
 skirt9_amd/lib/libskirthost.so: $(HOST_LIB_SRC) $(HOST_HDR)
 	@mkdir -p skirt9_amd/lib
-	$(CXX) $(CXXFLAGS) -shared $(HOST_LIB_SRC) -o $@
+	$(CXX) $(CXXFLAGS) -pthread -shared $(HOST_LIB_SRC) -o $@
 
 skirt9_amd/lib/libpmc.so: $(wildcard skirt9_amd/csrc/*.hip) $(wildcard skirt9_amd/csrc/*.h) $(wildcard skirt9_amd/csrc/*.inc) $(wildcard include/*.h)
 	@mkdir -p skirt9_amd/lib
@@ -28,7 +28,7 @@ skirt9_amd/lib/libpmc_prof.so: $(wildcard skirt9_amd/csrc/*.hip) $(wildcard skir
 	$(HIPCC) $(HIPFLAGS) -DPMC_PROFILE -shared $(wildcard skirt9_amd/csrc/*.hip) -o $@
 
 skirt9_amd/lib/skirt_mi355x: skirt9_amd/host/main.cpp skirt9_amd/lib/libskirthost.so skirt9_amd/lib/libpmc.so
-	$(CXX) $(CXXFLAGS) skirt9_amd/host/main.cpp -Lskirt9_amd/lib -lskirthost -lpmc -Wl,-rpath,'$$ORIGIN' -o $@
+	$(CXX) $(CXXFLAGS) skirt9_amd/host/main.cpp -Lskirt9_amd/lib -lskirthost -lpmc -pthread -Wl,-rpath,'$$ORIGIN' -o $@
 
 # ---- test oracle (never part of `all`)
 oracle: oracle/_build/liboracle.so

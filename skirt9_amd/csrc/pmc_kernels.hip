@@ -55,6 +55,12 @@
     #define PMC_WALK_REFILL 40  // waiting (idle or pending) lanes in a wave that trigger a service round (a round costs
                                 // several hundred instructions whatever the number of lanes it serves)
 #endif
+#ifndef PMC_WALK_MIN_WAVES
+    #define PMC_WALK_MIN_WAVES 1  // waves per SIMD the walk kernel's register budget must allow
+#endif
+#ifndef PMC_TRANSITION_MIN_WAVES
+    #define PMC_TRANSITION_MIN_WAVES 1  // likewise for the transition and launch kernels
+#endif
 #ifndef PMC_WALK_STEPS
     #define PMC_WALK_STEPS 4  // steps between two service checks
 #endif

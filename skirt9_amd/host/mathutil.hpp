@@ -13,7 +13,10 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
+#include <functional>
 #include <random>
+#include <thread>
 #include <vector>
 
 namespace skh
@@ -202,6 +205,29 @@ namespace skh
             }
             return norm;
         }
+    }
+
+    // Runs body(begin, end) over [0, n) on the host cores (SKH_THREADS overrides the count).  Used for the density
+    // evaluations of the setup phase only: the sample POSITIONS are drawn sequentially from the one random stream, in the
+    // reference's order, and every evaluation is independent, so the results do not depend on the thread count.
+    inline void parallelFor(size_t n, const std::function<void(size_t, size_t)>& body)
+    {
+        size_t threads = std::thread::hardware_concurrency();
+        if (const char* env = std::getenv("SKH_THREADS")) threads = static_cast<size_t>(std::max(1, atoi(env)));
+        threads = std::max<size_t>(1, std::min<size_t>(threads, n / 256));
+        if (threads <= 1)
+        {
+            body(0, n);
+            return;
+        }
+        std::vector<std::thread> pool;
+        const size_t chunk = (n + threads - 1) / threads;
+        for (size_t t = 0; t != threads; ++t)
+        {
+            const size_t b = t * chunk, e = std::min(n, b + chunk);
+            if (b < e) pool.emplace_back(body, b, e);
+        }
+        for (auto& th : pool) th.join();
     }
 
     // The parent-thread generator of the reference: seeded from <Random seed="..."/> (Random.cpp:40-46), one

@@ -398,12 +398,12 @@ namespace skh
     // DensityTreePolicy::needsSubdivide + constructTree (DensityTreePolicy.cpp:117-231,245-309) for a single dust
     // medium without MassInBoxInterface, executed by one thread (SerialParallel) so that the random stream is
     // consumed in node order
-    void OctreeSpatialGrid::setup(const GeometricMedium& medium, int numDensitySamples, Random& random)
+    void OctreeSpatialGrid::setup(const Medium& medium, int numDensitySamples, Random& random)
     {
         bool hasDustFraction = maxDustFraction > 0;
         bool hasDustOpticalDepth = maxDustOpticalDepth > 0;
         bool hasDustDensityDispersion = maxDustDensityDispersion > 0;
-        double dustMass = hasDustFraction ? medium.mass : 0.;
+        double dustMass = hasDustFraction ? medium.totalMass() : 0.;
         double dustKappa = 0.;
         if (hasDustOpticalDepth) dustKappa = medium.mix->sectionExt(policyWavelength) / medium.mix->mass();
 
@@ -412,43 +412,63 @@ namespace skh
         root.box = extent;
         nodes.push_back(root);
 
+        // a level is evaluated in batches: the sample positions of a batch are drawn from the random stream node by
+        // node (the order in which one reference thread consumes it), the densities are evaluated on all host cores
+        const size_t batchNodes = std::max<size_t>(1, (size_t(1) << 22) / std::max(1, numDensitySamples));
+        std::vector<Vec3> pos;
+        std::vector<double> rhov;
         size_t lbeg = 0, lend = 1;
         while (lend != lbeg)
         {
             size_t numEvalNodes = lend - lbeg;
             std::vector<char> divide(numEvalNodes, 0);
-            for (size_t l = 0; l != numEvalNodes; ++l)
+            for (size_t b0 = 0; b0 < numEvalNodes; b0 += batchNodes)
             {
-                const Node& node = nodes[lbeg + l];
-                bool need = false;
-                if (node.level < minLevel)
-                    need = true;
-                else if (node.level >= maxLevel)
-                    need = false;
-                else
+                const size_t b1 = std::min(numEvalNodes, b0 + batchNodes);
+                pos.clear();
+                for (size_t l = b0; l != b1; ++l)
                 {
-                    double rhomin = DBL_MAX, rhomax = 0., rhosum = 0;
-                    for (int i = 0; i != numDensitySamples; ++i)
-                    {
-                        Vec3 r = random.position(node.box);
-                        double rhoi = 0.;
-                        rhoi += medium.massDensity(r);
-                        rhosum += rhoi;
-                        if (rhoi < rhomin) rhomin = rhoi;
-                        if (rhoi > rhomax) rhomax = rhoi;
-                    }
-                    double rho = rhosum / numDensitySamples;
-                    double V = node.box.volume();
-                    double M = rho * V;
-                    if (hasDustFraction && M / dustMass > maxDustFraction) need = true;
-                    if (!need && hasDustOpticalDepth && dustKappa * rho * node.box.diagonal() > maxDustOpticalDepth) need = true;
-                    if (!need && hasDustDensityDispersion)
-                    {
-                        double q = rhomax > 0 ? (rhomax - rhomin) / rhomax : 0.;
-                        if (q > maxDustDensityDispersion) need = true;
-                    }
+                    const Node& node = nodes[lbeg + l];
+                    if (node.level >= minLevel && node.level < maxLevel)
+                        for (int i = 0; i != numDensitySamples; ++i) pos.push_back(random.position(node.box));
                 }
-                divide[l] = need;
+                rhov.resize(pos.size());
+                parallelFor(pos.size(), [&](size_t b, size_t e) {
+                    for (size_t i = b; i != e; ++i) rhov[i] = medium.massDensity(pos[i]);
+                });
+                size_t at = 0;
+                for (size_t l = b0; l != b1; ++l)
+                {
+                    const Node& node = nodes[lbeg + l];
+                    bool need = false;
+                    if (node.level < minLevel)
+                        need = true;
+                    else if (node.level >= maxLevel)
+                        need = false;
+                    else
+                    {
+                        double rhomin = DBL_MAX, rhomax = 0., rhosum = 0;
+                        for (int i = 0; i != numDensitySamples; ++i)
+                        {
+                            double rhoi = 0.;
+                            rhoi += rhov[at++];
+                            rhosum += rhoi;
+                            if (rhoi < rhomin) rhomin = rhoi;
+                            if (rhoi > rhomax) rhomax = rhoi;
+                        }
+                        double rho = rhosum / numDensitySamples;
+                        double V = node.box.volume();
+                        double M = rho * V;
+                        if (hasDustFraction && M / dustMass > maxDustFraction) need = true;
+                        if (!need && hasDustOpticalDepth && dustKappa * rho * node.box.diagonal() > maxDustOpticalDepth) need = true;
+                        if (!need && hasDustDensityDispersion)
+                        {
+                            double q = rhomax > 0 ? (rhomax - rhomin) / rhomax : 0.;
+                            if (q > maxDustDensityDispersion) need = true;
+                        }
+                    }
+                    divide[l] = need;
+                }
             }
             for (size_t l = 0; l != numEvalNodes; ++l)
                 if (divide[l]) subdivide(static_cast<int>(lbeg + l));

@@ -8,6 +8,7 @@
 
 #include "../../include/pmc.h"
 #include "mathutil.hpp"
+#include "particles.hpp"
 #include "xml.hpp"
 #include <memory>
 #include <string>
@@ -150,13 +151,28 @@ namespace skh
 
     // ---------------------------------------------------------------- medium
 
+    // what the grid policy and the density sampling ask of a medium (SKIRT/core/Medium.hpp)
+    class Medium
+    {
+    public:
+        virtual ~Medium() {}
+        std::unique_ptr<DustMix> mix;
+        virtual std::string type() const = 0;
+        virtual void setup() = 0;
+        virtual double numberDensity(Vec3 r) const = 0;
+        virtual double massDensity(Vec3 r) const = 0;
+        virtual double totalMass() const = 0;
+        virtual double totalNumber() const = 0;
+        // wavelength that the medium's normalisation adds to the simulation wavelengths (0: none)
+        virtual double normalizationWavelength() const { return 0.; }
+    };
+
     // GeometricMedium with OpticalDepth/Mass/Number material normalisation
     // SKIRT/core/GeometricMedium.cpp:13-18,128-131; OpticalDepthMaterialNormalization.cpp:13-27
-    class GeometricMedium
+    class GeometricMedium : public Medium
     {
     public:
         std::unique_ptr<Geometry> geometry;
-        std::unique_ptr<DustMix> mix;
         std::string normType;  // OpticalDepthMaterialNormalization | MassMaterialNormalization | NumberMaterialNormalization
         char normAxis{'Z'};
         double normWavelength{0.55e-6};
@@ -165,9 +181,53 @@ namespace skh
         double normNumber{0};
         double number{0}, mass{0};  // results of setup()
 
-        void setup();
-        double numberDensity(Vec3 r) const { return number * geometry->density(r); }
-        double massDensity(Vec3 r) const { return mass * geometry->density(r); }
+        std::string type() const override { return "GeometricMedium"; }
+        void setup() override;
+        double numberDensity(Vec3 r) const override { return number * geometry->density(r); }
+        double massDensity(Vec3 r) const override { return mass * geometry->density(r); }
+        double totalMass() const override { return mass; }
+        double totalNumber() const override { return number; }
+        double normalizationWavelength() const override
+        {
+            return normType == "OpticalDepthMaterialNormalization" ? normWavelength : 0.;
+        }
+    };
+
+    // ParticleMedium: a dust medium imported from smoothed particles (SKIRT/core/ParticleMedium.cpp:12-63,
+    // ImportedMedium.cpp:12-55,188-214); see particles.hpp
+    class ParticleMedium : public Medium
+    {
+    public:
+        ParticleImportOptions options;
+        std::string kernelType{"CubicSplineSmoothingKernel"};
+        ParticleSnapshot snapshot;
+
+        std::string type() const override { return "ParticleMedium"; }
+        void setup() override { snapshot.load(options, SmoothingKernel::create(kernelType)); }
+        double numberDensity(Vec3 r) const override
+        {
+            double result = snapshot.density(r);
+            if (!snapshot.holdsNumber()) result /= mix->mass();
+            return result;
+        }
+        double massDensity(Vec3 r) const override
+        {
+            double result = snapshot.density(r);
+            if (snapshot.holdsNumber()) result *= mix->mass();
+            return result;
+        }
+        double totalMass() const override
+        {
+            double result = snapshot.mass();
+            if (snapshot.holdsNumber()) result *= mix->mass();
+            return result;
+        }
+        double totalNumber() const override
+        {
+            double result = snapshot.mass();
+            if (!snapshot.holdsNumber()) result /= mix->mass();
+            return result;
+        }
     };
 
     // ---------------------------------------------------------------- spatial grids
@@ -219,7 +279,7 @@ namespace skh
         std::vector<int32_t> flatLevel, flatFirstChild, flatCell, flatNbrStart, flatNbrList;
 
         // builds the tree; consumes the random stream exactly like DensityTreePolicy::constructTree at one thread
-        void setup(const GeometricMedium& medium, int numDensitySamples, Random& random);
+        void setup(const Medium& medium, int numDensitySamples, Random& random);
         // builds the tree from a topology stream ("1"/"0" per node, depth first; TreeSpatialGrid.cpp:225-251) --
         // the node ids are then assigned breadth-first as the policy would have done for the same topology
         void setupFromTopology(const std::vector<char>& topology);

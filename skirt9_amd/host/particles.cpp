@@ -1,0 +1,385 @@
+// particles.cpp -- see particles.hpp
+#include "particles.hpp"
+#include "units.hpp"
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <regex>
+#include <sstream>
+#include <stdexcept>
+
+namespace skh
+{
+    // ================================================================ smoothing kernels
+
+    namespace
+    {
+        // CubicSplineSmoothingKernel.cpp:40-50
+        class CubicSplineSmoothingKernel : public SmoothingKernel
+        {
+        public:
+            std::string type() const override { return "CubicSplineSmoothingKernel"; }
+            double density(double u) const override
+            {
+                if (u < 0.0 || u >= 1.0)
+                    return 0.0;
+                else if (u < 0.5)
+                    return 8.0 / M_PI * (1.0 - 6.0 * u * u * (1.0 - u));
+                else
+                    return 8.0 / M_PI * 2.0 * (1.0 - u) * (1.0 - u) * (1.0 - u);
+            }
+        };
+        // ScaledGaussianSmoothingKernel.cpp:16-47
+        class ScaledGaussianSmoothingKernel : public SmoothingKernel
+        {
+        public:
+            std::string type() const override { return "ScaledGaussianSmoothingKernel"; }
+            double density(double u) const override
+            {
+                constexpr double N = 2.56810060330949540082;
+                constexpr double A = -5.85836755024609305208;
+                if (u < 0. || u > 1.) return 0.;
+                return N * exp(A * u * u);
+            }
+        };
+        // UniformSmoothingKernel.cpp:13-17
+        class UniformSmoothingKernel : public SmoothingKernel
+        {
+        public:
+            std::string type() const override { return "UniformSmoothingKernel"; }
+            double density(double u) const override
+            {
+                if (u < 0.0 || u > 1.0) return 0.0;
+                return 0.75 / M_PI;
+            }
+        };
+    }
+
+    std::unique_ptr<SmoothingKernel> SmoothingKernel::create(const std::string& type)
+    {
+        if (type == "CubicSplineSmoothingKernel") return std::make_unique<CubicSplineSmoothingKernel>();
+        if (type == "ScaledGaussianSmoothingKernel") return std::make_unique<ScaledGaussianSmoothingKernel>();
+        if (type == "UniformSmoothingKernel") return std::make_unique<UniformSmoothingKernel>();
+        throw std::runtime_error("smoothing kernel " + type + " is not supported on the MI355X path");
+    }
+
+    // ================================================================ BoxSearch
+
+    namespace
+    {
+        // BoxSearch.cpp:14-52
+        void makegrid(Array& grid, const std::vector<Box>& boxv, int axis, int gridsize, double cmin, double cmax)
+        {
+            if (cmin == cmax)
+            {
+                double eps = 1e-12 * (cmin ? std::abs(cmin) : 1.);
+                cmin -= eps;
+                cmax += eps;
+            }
+            int nbins = gridsize * 100;
+            double binwidth = (cmax - cmin) / nbins;
+            std::vector<int> bins(nbins);
+            for (const auto& box : boxv)
+            {
+                double center = 0.;
+                switch (axis)
+                {
+                    case 1: center = 0.5 * (box.xmin + box.xmax); break;
+                    case 2: center = 0.5 * (box.ymin + box.ymax); break;
+                    case 3: center = 0.5 * (box.zmin + box.zmax); break;
+                }
+                bins[static_cast<int>((center - cmin) / binwidth)] += 1;
+            }
+            double perblock = static_cast<double>(boxv.size()) / gridsize;
+            grid.assign(gridsize + 1, 0.);
+            grid[0] = -std::numeric_limits<double>::infinity();
+            int cumul = 0;
+            int gridindex = 1;
+            for (int binindex = 0; binindex < nbins; binindex++)
+            {
+                cumul += bins[binindex];
+                if (cumul > perblock * gridindex)
+                {
+                    grid[gridindex] = cmin + (binindex + 1) * binwidth;
+                    gridindex += 1;
+                    if (gridindex >= gridsize) break;
+                }
+            }
+            grid[gridsize] = std::numeric_limits<double>::infinity();
+        }
+
+        inline double square(double x) { return x * x; }
+        // Box::intersects(Vec rc, double r) (SKIRT/utils/Box.cpp:91-109)
+        bool boxIntersectsSphere(const Box& b, double cx, double cy, double cz, double r)
+        {
+            double squaredist = square(r);
+            if (cx < b.xmin)
+                squaredist -= square(cx - b.xmin);
+            else if (cx > b.xmax)
+                squaredist -= square(cx - b.xmax);
+            if (cy < b.ymin)
+                squaredist -= square(cy - b.ymin);
+            else if (cy > b.ymax)
+                squaredist -= square(cy - b.ymax);
+            if (cz < b.zmin)
+                squaredist -= square(cz - b.zmin);
+            else if (cz > b.zmax)
+                squaredist -= square(cz - b.zmax);
+            return squaredist >= 0.;
+        }
+    }
+
+    template<class Bounds, class Intersects> void BoxSearch::loadEntities(int numEntities, Bounds bounds, Intersects intersects)
+    {
+        _listv.clear();
+        if (numEntities <= 0)
+        {
+            _extent = Box();
+            _numBlocks = 0;
+            return;
+        }
+        std::vector<Box> boxv;
+        boxv.reserve(numEntities);
+        for (int m = 0; m != numEntities; ++m) boxv.emplace_back(bounds(m));
+        _extent = boxv[0];
+        for (const auto& box : boxv)
+        {
+            _extent.xmin = std::min(_extent.xmin, box.xmin);
+            _extent.ymin = std::min(_extent.ymin, box.ymin);
+            _extent.zmin = std::min(_extent.zmin, box.zmin);
+            _extent.xmax = std::max(_extent.xmax, box.xmax);
+            _extent.ymax = std::max(_extent.ymax, box.ymax);
+            _extent.zmax = std::max(_extent.zmax, box.zmax);
+        }
+        _numBlocks = std::max(10, static_cast<int>(std::cbrt(numEntities)));
+        makegrid(_xgrid, boxv, 1, _numBlocks, _extent.xmin, _extent.xmax);
+        makegrid(_ygrid, boxv, 2, _numBlocks, _extent.ymin, _extent.ymax);
+        makegrid(_zgrid, boxv, 3, _numBlocks, _extent.zmin, _extent.zmax);
+        _listv.resize(static_cast<size_t>(_numBlocks) * _numBlocks * _numBlocks);
+        for (int m = 0; m != numEntities; ++m)
+        {
+            const auto& box = boxv[m];
+            int i1 = nr::locateClip(_xgrid, box.xmin);
+            int i2 = nr::locateClip(_xgrid, box.xmax);
+            int j1 = nr::locateClip(_ygrid, box.ymin);
+            int j2 = nr::locateClip(_ygrid, box.ymax);
+            int k1 = nr::locateClip(_zgrid, box.zmin);
+            int k2 = nr::locateClip(_zgrid, box.zmax);
+            for (int i = i1; i <= i2; i++)
+                for (int j = j1; j <= j2; j++)
+                    for (int k = k1; k <= k2; k++)
+                    {
+                        Box block(_xgrid[i], _ygrid[j], _zgrid[k], _xgrid[i + 1], _ygrid[j + 1], _zgrid[k + 1]);
+                        if (intersects(m, block)) _listv[blockIndex(i, j, k)].push_back(m);
+                    }
+        }
+    }
+
+    const std::vector<int>& BoxSearch::entitiesFor(Vec3 r) const
+    {
+        if (!_numBlocks) return _empty;
+        int i = nr::locateClip(_xgrid, r.x);
+        int j = nr::locateClip(_ygrid, r.y);
+        int k = nr::locateClip(_zgrid, r.z);
+        return _listv[blockIndex(i, j, k)];
+    }
+
+    size_t BoxSearch::numReferences() const
+    {
+        size_t n = 0;
+        for (const auto& l : _listv) n += l.size();
+        return n;
+    }
+
+    // ================================================================ column text file
+
+    namespace
+    {
+        std::string squeezeText(const std::string& text)
+        {
+            std::string out;
+            bool haveSpace = true;
+            for (char c : text)
+            {
+                if (c == ' ' || c == '\t' || c == '\n' || c == '\r')
+                {
+                    if (!haveSpace)
+                    {
+                        out.push_back(' ');
+                        haveSpace = true;
+                    }
+                }
+                else
+                {
+                    out.push_back(c);
+                    haveSpace = false;
+                }
+            }
+            if (haveSpace && !out.empty()) out.pop_back();
+            return out;
+        }
+    }
+
+    std::vector<Array> readColumnFile(const std::string& path, const std::vector<ColumnSpec>& columns)
+    {
+        std::ifstream in(path);
+        if (!in) throw std::runtime_error("Could not open the smoothed particles text file " + path);
+        // ---- header: "# column N: description (unit)" lines (TextInFile.cpp:16-47,87-101); other '#' lines are comments
+        struct FileColumn
+        {
+            std::string title, unit;
+        };
+        std::vector<FileColumn> fileCols;
+        static const std::regex syntax("#\\s*column\\s*(\\d*)\\s*:\\s*([^()]*)\\(\\s*([a-zA-Z0-9/]*)\\s*\\)\\s*", std::regex::icase);
+        while (true)
+        {
+            while (true)
+            {
+                int ch = in.peek();
+                if (ch != ' ' && ch != '\t' && ch != '\n' && ch != '\r') break;
+                in.get();
+            }
+            if (in.peek() != '#') break;
+            std::string line;
+            std::getline(in, line);
+            std::smatch matches;
+            if (std::regex_match(line, matches, syntax) && matches.size() == 4)
+            {
+                std::string index = matches[1].str();
+                fileCols.push_back(FileColumn{squeezeText(matches[2].str()), matches[3].str()});
+                if (!index.empty() && std::stoul(index) != fileCols.size())
+                    throw std::runtime_error("Incorrect column index in file header for column " + std::to_string(fileCols.size()));
+            }
+        }
+        // ---- logical columns in file order (TextInFile::addColumn without column remapping, :214-262)
+        const size_t ncol = columns.size();
+        std::vector<UnitFactor> conv(ncol);
+        for (size_t c = 0; c != ncol; ++c)
+        {
+            std::string unit = columns[c].defaultUnit;
+            if (!fileCols.empty())
+            {
+                if (c + 1 > fileCols.size()) throw std::runtime_error("No column info in file header for column " + std::to_string(c + 1));
+                unit = fileCols[c].unit;
+            }
+            if (columns[c].quantity.empty())
+            {
+                if (!unit.empty() && unit != "1")
+                    throw std::runtime_error("Invalid units (" + unit + ") for dimensionless quantity in column " + std::to_string(c + 1));
+                conv[c] = UnitFactor{1., 1., 0.};
+            }
+            else
+            {
+                if (!unitTable().has(columns[c].quantity, unit))
+                    throw std::runtime_error("Invalid units (" + unit + ") for quantity '" + columns[c].quantity + "' in column "
+                                             + std::to_string(c + 1));
+                conv[c] = unitTable().factorOf(columns[c].quantity, unit);
+            }
+        }
+        // ---- rows (TextInFile::readRow, :286-330): value = factor * value^power
+        std::vector<Array> rows;
+        std::string line;
+        while (std::getline(in, line))
+        {
+            auto pos = line.find_first_not_of(" \t\r");
+            if (pos == std::string::npos || line[pos] == '#') continue;
+            Array row(ncol);
+            const char* p = line.c_str() + pos;
+            for (size_t c = 0; c != ncol; ++c)
+            {
+                while (*p == ' ' || *p == '\t') ++p;
+                if (!*p || *p == '\r') throw std::runtime_error("One or more required value(s) on text line are missing");
+                char* end = nullptr;
+                double value = strtod(p, &end);
+                if (end == p)
+                {
+                    if (strncasecmp(p, "nan", 3) != 0)
+                        throw std::runtime_error(std::string("Input text is not formatted as a floating point number: ") + p);
+                    value = std::numeric_limits<double>::quiet_NaN();
+                    end = const_cast<char*>(p) + 3;
+                }
+                p = end;
+                if (conv[c].power != 1.) value = pow(value, conv[c].power);
+                value *= conv[c].factor;
+                row[c] = value;
+            }
+            rows.push_back(std::move(row));
+        }
+        return rows;
+    }
+
+    // ================================================================ ParticleSnapshot
+
+    void ParticleSnapshot::load(const ParticleImportOptions& o, std::unique_ptr<SmoothingKernel> kernel)
+    {
+        _kernel = std::move(kernel);
+        _holdsNumber = o.holdsNumber;
+        // column roles in the reference's order: ParticleMedium.cpp:19-30 then ImportedMedium.cpp:17-18
+        std::vector<ColumnSpec> cols = {{"position x", "length", "pc"}, {"position y", "length", "pc"}, {"position z", "length", "pc"},
+                                        {"size h", "length", "pc"}};
+        const int massIndex = 4;
+        if (o.holdsNumber)
+            cols.push_back({"number", "", ""});
+        else
+            cols.push_back({"mass", "mass", "Msun"});
+        int metallicityIndex = -1, temperatureIndex = -1;
+        if (o.importMetallicity)
+        {
+            metallicityIndex = static_cast<int>(cols.size());
+            cols.push_back({"metallicity", "", ""});
+        }
+        if (o.importTemperature)
+        {
+            temperatureIndex = static_cast<int>(cols.size());
+            cols.push_back({"temperature", "temperature", "K"});
+        }
+        // Snapshot::setMassDensityPolicy as called by ImportedMedium (dust: Tmax and metallicity apply; otherwise not)
+        const double maxTemperature = (o.isDust && o.importTemperature) ? o.maxTemperature : 0.;
+        const bool useMetallicity = o.isDust && o.importMetallicity && metallicityIndex >= 0;
+        const bool useTemperatureCutoff = maxTemperature > 0 && temperatureIndex >= 0;
+
+        std::vector<Array> rows = readColumnFile(o.path, cols);
+        // ParticleSnapshot::readAndClose (ParticleSnapshot.cpp:79-151)
+        _pv.clear();
+        _pv.reserve(rows.size());
+        double totalOriginalMass = 0, totalMetallicMass = 0, totalEffectiveMass = 0;
+        for (const Array& prop : rows)
+        {
+            if (useTemperatureCutoff && prop[temperatureIndex] > maxTemperature) continue;
+            if (prop[massIndex] == 0.) continue;
+            double originalMass = prop[massIndex];
+            double metallicMass = originalMass * (useMetallicity ? prop[metallicityIndex] : 1.);
+            double effectiveMass = metallicMass * o.massFraction;
+            _pv.push_back(Particle{prop[0], prop[1], prop[2], prop[3], effectiveMass});
+            totalOriginalMass += originalMass;
+            totalMetallicMass += metallicMass;
+            totalEffectiveMass += effectiveMass;
+        }
+        if (totalOriginalMass < 0 || totalMetallicMass < 0 || totalEffectiveMass < 0)
+        {
+            _pv.clear();
+            totalEffectiveMass = 0;
+        }
+        _mass = totalEffectiveMass;
+        _search.loadEntities(
+            static_cast<int>(_pv.size()),
+            [this](int m) {
+                const Particle& p = _pv[m];
+                return Box(p.x - p.h, p.y - p.h, p.z - p.h, p.x + p.h, p.y + p.h, p.z + p.h);
+            },
+            [this](int m, const Box& box) { return boxIntersectsSphere(box, _pv[m].x, _pv[m].y, _pv[m].z, _pv[m].h); });
+    }
+
+    double ParticleSnapshot::density(Vec3 r) const
+    {
+        double sum = 0.;
+        for (int m : _search.entitiesFor(r))
+        {
+            const Particle& p = _pv[m];
+            const double dx = r.x - p.x, dy = r.y - p.y, dz = r.z - p.z;
+            double u = sqrt(dx * dx + dy * dy + dz * dz) / p.h;
+            sum += _kernel->density(u) * p.density();
+        }
+        return sum > 0. ? sum : 0.;
+    }
+}

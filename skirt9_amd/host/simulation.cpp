@@ -122,15 +122,20 @@ namespace skh
         if (slash != std::string::npos) base = base.substr(slash + 1);
         size_t dot = base.find_last_of('.');
         if (dot != std::string::npos) base = base.substr(0, dot);
-        return fromString(ss.str(), base);
+        // input files named in the ski are looked up in the ski file's directory (the reference: FilePaths::input, i.e.
+        // the -i directory or the working directory; SKH_INPUT_PATH overrides)
+        std::string dir = slash != std::string::npos ? path.substr(0, slash) : std::string(".");
+        if (const char* env = getenv("SKH_INPUT_PATH")) dir = env;
+        return fromString(ss.str(), base, dir);
     }
 
-    std::unique_ptr<Simulation> Simulation::fromString(const std::string& text, const std::string& prefix)
+    std::unique_ptr<Simulation> Simulation::fromString(const std::string& text, const std::string& prefix, const std::string& inputPath)
     {
         XmlParser parser(text);
         auto root = parser.parseDocument();
         std::unique_ptr<Simulation> sim(new Simulation());
         sim->_prefix = prefix;
+        sim->_inputPath = inputPath;
         sim->parse(*root);
         return sim;
     }
@@ -259,40 +264,66 @@ namespace skh
         auto media = ms->items("media");
         if (media.size() != 1) unsupported("a medium system with " + std::to_string(media.size()) + " media");
         const XmlElement& med = *media[0];
-        if (med.name != "GeometricMedium") unsupported("medium " + med.name);
+        if (med.name != "GeometricMedium" && med.name != "ParticleMedium") unsupported("medium " + med.name);
         if (med.item("velocityDistribution") && rd.quantity(med, "velocityMagnitude", "velocity", "0") && !_oligo)
             unsupported("a medium with a velocity field");
         if (med.item("magneticFieldDistribution") && rd.quantity(med, "magneticFieldStrength", "magneticfield", "0"))
             unsupported("a medium with a magnetic field");
-        _medium = std::make_unique<GeometricMedium>();
-        const XmlElement* mg = med.item("geometry");
-        if (!mg) throw std::runtime_error("ski: GeometricMedium lacks a geometry");
-        _medium->geometry = makeGeometry(*mg, rd);
         const XmlElement* mm = med.item("materialMix");
-        if (!mm) throw std::runtime_error("ski: GeometricMedium lacks a material mix");
+        if (!mm) throw std::runtime_error("ski: " + med.name + " lacks a material mix");
         if (mm->name != "MeanListDustMix") unsupported("material mix " + mm->name);
-        _medium->mix = std::make_unique<DustMix>();
-        _medium->mix->typeName = mm->name;
-        _medium->mix->inLambda = rd.list(*mm, "wavelengths", "wavelength", "");
-        _medium->mix->inKappaExt = rd.list(*mm, "extinctionCoefficients", "masscoefficient", "");
-        _medium->mix->inAlbedo = rd.list(*mm, "albedos", "", "");
-        _medium->mix->inAsymmpar = rd.list(*mm, "asymmetryParameters", "", "");
-        const XmlElement* mn = med.item("normalization");
-        if (!mn) throw std::runtime_error("ski: GeometricMedium lacks a normalization");
-        _medium->normType = mn->name;
-        if (mn->name == "OpticalDepthMaterialNormalization")
+        auto mix = std::make_unique<DustMix>();
+        mix->typeName = mm->name;
+        mix->inLambda = rd.list(*mm, "wavelengths", "wavelength", "");
+        mix->inKappaExt = rd.list(*mm, "extinctionCoefficients", "masscoefficient", "");
+        mix->inAlbedo = rd.list(*mm, "albedos", "", "");
+        mix->inAsymmpar = rd.list(*mm, "asymmetryParameters", "", "");
+        if (med.name == "GeometricMedium")
         {
-            std::string axis = mn->attr("axis", "Z");
-            _medium->normAxis = axis.empty() ? 'Z' : axis[0];
-            _medium->normWavelength = rd.quantity(*mn, "wavelength", "wavelength");
-            _medium->normOpticalDepth = rd.number(*mn, "opticalDepth");
+            auto gm = std::make_unique<GeometricMedium>();
+            const XmlElement* mg = med.item("geometry");
+            if (!mg) throw std::runtime_error("ski: GeometricMedium lacks a geometry");
+            gm->geometry = makeGeometry(*mg, rd);
+            const XmlElement* mn = med.item("normalization");
+            if (!mn) throw std::runtime_error("ski: GeometricMedium lacks a normalization");
+            gm->normType = mn->name;
+            if (mn->name == "OpticalDepthMaterialNormalization")
+            {
+                std::string axis = mn->attr("axis", "Z");
+                gm->normAxis = axis.empty() ? 'Z' : axis[0];
+                gm->normWavelength = rd.quantity(*mn, "wavelength", "wavelength");
+                gm->normOpticalDepth = rd.number(*mn, "opticalDepth");
+            }
+            else if (mn->name == "MassMaterialNormalization")
+                gm->normMass = rd.quantity(*mn, "mass", "mass");
+            else if (mn->name == "NumberMaterialNormalization")
+                gm->normNumber = rd.number(*mn, "number");
+            else
+                unsupported("material normalization " + mn->name);
+            _medium = std::move(gm);
         }
-        else if (mn->name == "MassMaterialNormalization")
-            _medium->normMass = rd.quantity(*mn, "mass", "mass");
-        else if (mn->name == "NumberMaterialNormalization")
-            _medium->normNumber = rd.number(*mn, "number");
         else
-            unsupported("material normalization " + mn->name);
+        {
+            // ParticleMedium (ParticleMedium.hpp, ImportedMedium.hpp): a text column file of smoothed particles
+            auto pm = std::make_unique<ParticleMedium>();
+            std::string filename = med.attr("filename", "");
+            if (filename.empty()) throw std::runtime_error("ski: ParticleMedium lacks a filename");
+            pm->options.path = (filename[0] == '/') ? filename : _inputPath + "/" + filename;
+            std::string massType = med.attr("massType", "Mass");
+            if (massType != "Mass" && massType != "Number") unsupported("massType " + massType);
+            pm->options.holdsNumber = massType == "Number";
+            pm->options.massFraction = rd.number(med, "massFraction", "1");
+            pm->options.importMetallicity = rd.boolean(med, "importMetallicity", false);
+            pm->options.importTemperature = rd.boolean(med, "importTemperature", false);
+            pm->options.maxTemperature = rd.quantity(med, "maxTemperature", "temperature", "0 K");
+            if (rd.boolean(med, "importVelocity", false) && !_oligo) unsupported("an imported medium with a velocity field");
+            if (rd.boolean(med, "importMagneticField", false)) unsupported("an imported medium with a magnetic field");
+            if (rd.boolean(med, "importVariableMixParams", false)) unsupported("an imported medium with a variable material mix");
+            if (!med.attr("useColumns", "").empty()) unsupported("useColumns (column remapping)");
+            if (const XmlElement* sk = med.item("smoothingKernel")) pm->kernelType = sk->name;
+            _medium = std::move(pm);
+        }
+        _medium->mix = std::move(mix);
 
         const XmlElement* ge = ms->item("grid");
         if (!ge) throw std::runtime_error("ski: MediumSystem lacks a spatial grid");
@@ -417,10 +448,10 @@ namespace skh
         for (auto& ins : _instruments)
             if (ins.ownGrid) addGrid(ins.ownGrid.get());
         // MaterialWavelengthRangeInterface items: the normalisation wavelength and the tree policy wavelength
-        if (_medium->normType == "OpticalDepthMaterialNormalization" && _medium->normWavelength > 0)
+        if (_medium->normalizationWavelength() > 0)
         {
-            extend(_medium->normWavelength, _medium->normWavelength);
-            simWavelengths.insert(_medium->normWavelength);
+            extend(_medium->normalizationWavelength(), _medium->normalizationWavelength());
+            simWavelengths.insert(_medium->normalizationWavelength());
         }
         if (auto tree = dynamic_cast<OctreeSpatialGrid*>(_grid.get()))
             if (tree->maxDustOpticalDepth > 0 && tree->policyWavelength > 0)
@@ -449,18 +480,36 @@ namespace skh
         // MediumSystem::setupSelfAfter density sampling (MediumSystem.cpp:80-106,308-321)
         int numCells = _grid->numCells();
         _density.assign(numCells, 0.);
-        for (int m = 0; m != numCells; ++m)
+        if (_numDensitySamples == 1)
         {
-            Box box = _grid->cellBox(m);
-            if (_numDensitySamples == 1)
-                _density[m] = _medium->numberDensity(box.center());
-            else
+            for (int m = 0; m != numCells; ++m) _density[m] = _medium->numberDensity(_grid->cellBox(m).center());
+        }
+        else
+        {
+            // positions from the random stream in cell order, densities on all host cores, sums in sample order
+            const int batchCells = std::max(1, (1 << 22) / _numDensitySamples);
+            std::vector<Vec3> pos;
+            std::vector<double> samples;
+            for (int m0 = 0; m0 < numCells; m0 += batchCells)
             {
-                double sum = 0.;
-                std::vector<double> samples(_numDensitySamples);
-                for (int n = 0; n != _numDensitySamples; ++n) samples[n] = _medium->numberDensity(_random.position(box));
-                for (int n = 0; n != _numDensitySamples; ++n) sum += samples[n];
-                _density[m] = sum / _numDensitySamples;
+                const int m1 = std::min(numCells, m0 + batchCells);
+                pos.clear();
+                for (int m = m0; m != m1; ++m)
+                {
+                    Box box = _grid->cellBox(m);
+                    for (int n = 0; n != _numDensitySamples; ++n) pos.push_back(_random.position(box));
+                }
+                samples.resize(pos.size());
+                parallelFor(pos.size(), [&](size_t b, size_t e) {
+                    for (size_t i = b; i != e; ++i) samples[i] = _medium->numberDensity(pos[i]);
+                });
+                size_t at = 0;
+                for (int m = m0; m != m1; ++m)
+                {
+                    double sum = 0.;
+                    for (int n = 0; n != _numDensitySamples; ++n) sum += samples[at++];
+                    _density[m] = sum / _numDensitySamples;
+                }
             }
         }
 

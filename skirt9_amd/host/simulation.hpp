@@ -16,7 +16,8 @@ namespace skh
     public:
         // parse the ski file and construct the item tree (XmlHierarchyCreator::readFile)
         static std::unique_ptr<Simulation> fromFile(const std::string& path);
-        static std::unique_ptr<Simulation> fromString(const std::string& text, const std::string& prefix);
+        static std::unique_ptr<Simulation> fromString(const std::string& text, const std::string& prefix,
+                                                      const std::string& inputPath = ".");
 
         // Simulation::setupSimulation: builds grids, densities, tables; consumes the parent random stream
         // exactly as the reference does with one thread.  If treeTopologyFile is non-empty the octree is rebuilt
@@ -45,7 +46,7 @@ namespace skh
 
         // model objects, exposed for tests
         const SpatialGrid& grid() const { return *_grid; }
-        const GeometricMedium& medium() const { return *_medium; }
+        const Medium& medium() const { return *_medium; }
         const Array& numberDensity() const { return _density; }
         const SourceModel& source() const { return _source; }
 
@@ -59,6 +60,7 @@ namespace skh
         void buildScene();
 
         std::string _prefix;
+        std::string _inputPath{"."};
         OutputUnits _units;
         int _seed{0};
         Random _random;
@@ -71,7 +73,7 @@ namespace skh
         // medium system
         pmc_options _options{};
         int _numDensitySamples{100};
-        std::unique_ptr<GeometricMedium> _medium;
+        std::unique_ptr<Medium> _medium;
         std::unique_ptr<SpatialGrid> _grid;
         std::vector<char> _topology;
         Array _density;

@@ -139,6 +139,12 @@ namespace skh
             if (u == s->second.end()) throw std::runtime_error("ski: no default unit for quantity " + qty);
             return u->second;
         }
+        bool has(const std::string& qty, const std::string& unit) const
+        {
+            auto q = _quantities.find(qty);
+            return q != _quantities.end() && q->second.count(unit) != 0;
+        }
+        const UnitFactor& factorOf(const std::string& qty, const std::string& unit) const { return find(qty, unit); }
         // UnitDef::in (UnitDef.cpp:64-80)
         double in(const std::string& qty, const std::string& unit, double value) const
         {

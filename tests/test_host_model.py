@@ -35,7 +35,7 @@ def scene_head(sim):
     return SceneHead.from_address(sim.scene)
 
 
-@pytest.mark.parametrize("name,cells,nodes", [("cfg1", 32768, 0), ("cfg2small", 17592, 20105)])
+@pytest.mark.parametrize("name,cells,nodes", [("cfg1", 32768, 0), ("cfg2small", 17592, 20105), ("cfg4small", 7274, 8313)])
 def test_cell_densities_bit_exact(name, cells, nodes):
     sim = Simulation(ski(name + ".ski")).setup()
     head = scene_head(sim)
@@ -136,3 +136,76 @@ def test_fits_layout(tmp_path):
     assert np.count_nonzero(data) == 1 and data[5] > 0
     total = np.frombuffer(open(tmp_path / "cfg1_i0_total.fits", "rb").read()[2880:2880 + 4 * 4096], dtype=">f4")
     assert total[5] == data[5]
+
+
+# ---------------------------------------------------------------- smoothed-particle import (config 4)
+
+def _particle_ski(tmp_path, body, extra=""):
+    """cfg4small.ski with its particle file replaced by `body` and extra ParticleMedium attributes"""
+    text = open(ski("cfg4small.ski")).read().replace('filename="cfg4small_sph.txt"', 'filename="p.txt" ' + extra)
+    text = text.replace('maxLevel="7"', 'maxLevel="3"')
+    (tmp_path / "p.txt").write_text(body)
+    path = tmp_path / "p.ski"
+    path.write_text(text)
+    return str(path)
+
+
+def _densities(sim):
+    head = scene_head(sim)
+    return np.ctypeslib.as_array(head.medium.number_density, shape=(head.grid.num_cells,)).copy()
+
+
+def test_particle_file_units_and_defaults(tmp_path):
+    """the unit header of a column text file is honoured (TextInFile.cpp:16-47), and without a header the columns carry
+    the default units of their role (Snapshot.cpp:62-85,130-134: pc, pc, pc, pc, Msun)"""
+    rows = [(100.0, -200.0, 50.0, 3000.0, 2.0), (-4000.0, 1000.0, -100.0, 2500.0, 1.0), (0.0, 0.0, 0.0, 1000.0, 0.5)]
+    plain = "".join("%g %g %g %g %g\n" % r for r in rows)
+    kpc = ("# Column 1: position x (kpc)\n# column 2 : position y (kpc)\n#Column 3: position z (kpc)\n"
+           "# a comment line\n# Column 4: size h (kpc)\n# Column 5: mass (kg)\n"
+           + "".join("%.17g %.17g %.17g %.17g %.17g\n" % (r[0] / 1e3, r[1] / 1e3, r[2] / 1e3, r[3] / 1e3, r[4] * 1.9891e30)
+                     for r in rows))
+    d0 = _densities(Simulation(_particle_ski(tmp_path, plain)).setup())
+    d1 = _densities(Simulation(_particle_ski(tmp_path, kpc)).setup())
+    assert d0.max() > 0
+    assert np.allclose(d0, d1, rtol=1e-12, atol=0)
+
+
+def test_particle_mass_policy(tmp_path):
+    """massFraction scales, metallicity multiplies and the temperature cut-off drops particles
+    (ImportedMedium.cpp:44-52, ParticleSnapshot.cpp:57-69,92-108); zero-mass particles are ignored"""
+    base = "0 0 0 4000 1\n3000 0 0 4000 1\n"
+    d = _densities(Simulation(_particle_ski(tmp_path, base)).setup())
+    path = _particle_ski(tmp_path, base)
+    open(path, "w").write(open(path).read().replace('massFraction="1"', 'massFraction="0.5"'))
+    half = _densities(Simulation(path).setup())
+    assert d.max() > 0 and np.array_equal(half, 0.5 * d)
+    text = open(ski("cfg4small.ski")).read().replace('filename="cfg4small_sph.txt"', 'filename="p.txt"')
+    text = text.replace('maxLevel="7"', 'maxLevel="3"')
+    (tmp_path / "p.txt").write_text("0 0 0 4000 1 0.5 100\n3000 0 0 4000 1 0.5 1e6\n0 0 0 4000 0 1 100\n")
+    t2 = text.replace('importMetallicity="false"', 'importMetallicity="true"').replace(
+        'importTemperature="false"', 'importTemperature="true"').replace('maxTemperature="0 K"', 'maxTemperature="1e4 K"')
+    (tmp_path / "q.ski").write_text(t2)
+    dq = _densities(Simulation(str(tmp_path / "q.ski")).setup())
+    (tmp_path / "p.txt").write_text("0 0 0 4000 0.5\n")
+    (tmp_path / "r.ski").write_text(text)
+    dr = _densities(Simulation(str(tmp_path / "r.ski")).setup())
+    assert dq.max() > 0 and np.allclose(dq, dr, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("body,message", [
+    ("1 2 3 4\n", "missing"),
+    ("1 2 x 4 5\n", "floating point"),
+    ("# Column 1: position x (furlong)\n# Column 2: position y (pc)\n# Column 3: position z (pc)\n"
+     "# Column 4: size h (pc)\n# Column 5: mass (Msun)\n1 2 3 4 5\n", "Invalid units"),
+    ("# Column 2: position x (pc)\n1 2 3 4 5\n", "Incorrect column index"),
+])
+def test_particle_file_errors(tmp_path, body, message):
+    with pytest.raises(Exception, match=message):
+        Simulation(_particle_ski(tmp_path, body)).setup()
+
+
+def test_missing_particle_file_fails_loudly(tmp_path):
+    text = open(ski("cfg4small.ski")).read().replace('filename="cfg4small_sph.txt"', 'filename="nope.txt"')
+    (tmp_path / "m.ski").write_text(text)
+    with pytest.raises(Exception, match="Could not open"):
+        Simulation(str(tmp_path / "m.ski")).setup()
