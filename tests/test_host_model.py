@@ -176,7 +176,8 @@ def test_particle_mass_policy(tmp_path):
     base = "0 0 0 4000 1\n3000 0 0 4000 1\n"
     d = _densities(Simulation(_particle_ski(tmp_path, base)).setup())
     path = _particle_ski(tmp_path, base)
-    open(path, "w").write(open(path).read().replace('massFraction="1"', 'massFraction="0.5"'))
+    text = open(path).read().replace('massFraction="1"', 'massFraction="0.5"')
+    open(path, "w").write(text)
     half = _densities(Simulation(path).setup())
     assert d.max() > 0 and np.array_equal(half, 0.5 * d)
     text = open(ski("cfg4small.ski")).read().replace('filename="cfg4small_sph.txt"', 'filename="p.txt"')
