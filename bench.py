@@ -54,16 +54,19 @@ def pmc_traffic(packets_per_step):
     return kib * 1024.0 / 2e7 * packets_per_step if kib else None
 
 
-def cpu_baseline(packets_per_core=100000):
+def cpu_baseline(ski_path=SKI, input_dir=None, packets_per_core=100000):
     """photon packets/s of the CPU path on this box's host cores, on a bounded sample (about 10-30 s)"""
     cores = min(os.cpu_count() or 1, 24)  # the reference caps a process at 24 threads (ParallelFactory.cpp:43-50)
     ref = os.path.join(ROOT, "oracle", "_ref", "release", "SKIRT", "main", "skirt_ref")
     if os.path.exists(ref):
         n = packets_per_core * cores
         with tempfile.TemporaryDirectory() as tmp:
-            text = open(SKI).read().replace('numPackets="1e5"', f'numPackets="{n}"')
+            text = open(ski_path).read().replace('numPackets="1e5"', f'numPackets="{n}"')
             ski = os.path.join(tmp, "cfg2cpu.ski")
             open(ski, "w").write(text)
+            if input_dir:  # input files named in the ski file are read from the working directory
+                for f in os.listdir(input_dir):
+                    os.symlink(os.path.join(input_dir, f), os.path.join(tmp, f))
             try:
                 subprocess.run([ref, "run", ski, "-t", str(cores), "-o", tmp], check=True, stdout=subprocess.DEVNULL,
                                stderr=subprocess.DEVNULL, timeout=900, cwd=tmp)
@@ -71,7 +74,7 @@ def cpu_baseline(packets_per_core=100000):
                 m = re.search(r"Finished primary emission in ([0-9.]+) s", log)
                 if m and float(m.group(1)) > 0:
                     return {"value": n / float(m.group(1)), "unit": "photon packets/s", "cores": cores, "kind": "reference",
-                            "sample": f"unmodified SKIRT 9 (oracle/_ref), cfg2.ski scene, {n} packets, -t {cores}; "
+                            "sample": f"unmodified SKIRT 9 (oracle/_ref), {os.path.basename(ski_path)} scene, {n} packets, -t {cores}; "
                                       f"'Finished primary emission' {m.group(1)} s"}
             except Exception as exc:  # noqa: BLE001 - the baseline is informational
                 sys.stderr.write(f"[bench] reference baseline failed: {exc}\n")
@@ -79,12 +82,12 @@ def cpu_baseline(packets_per_core=100000):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     from skirt9_amd.host import Simulation
-    sim = Simulation(SKI, num_packets=20000).setup()
+    sim = Simulation(ski_path, num_packets=20000).setup()
     t0 = time.time()
     O.run_primary(sim, 0, 20000, O.RNG_PHILOX, seed=1)
     dt = time.time() - t0
     return {"value": 20000 / dt, "unit": "photon packets/s", "cores": 1, "kind": "port",
-            "sample": "oracle/life_cycle.cpp, cfg2.ski scene, 20000 packets, 1 thread"}
+            "sample": f"oracle/life_cycle.cpp, {os.path.basename(ski_path)} scene, 20000 packets, 1 thread"}
 
 
 def main():
@@ -97,6 +100,10 @@ def main():
     ap.add_argument("--source", choices=["sersic", "uniform"], default="sersic",
                     help="sersic: cfg2.ski as is (the headline workload); uniform: the same scene with the Sersic source "
                          "replaced by a UniformBoxGeometry source of +-10 x +-10 x +-1 kpc (north_star's second source)")
+    ap.add_argument("--config", type=int, choices=[2, 4], default=2,
+                    help="2: BASELINE configs[1] (the headline workload, tests/ski/cfg2.ski); 4: BASELINE configs[3], the same "
+                         "Sersic source in dust imported from 10^6 smoothed particles (tests/ski/cfg4.ski; the particle file "
+                         "is regenerated by tools/make_sph.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -120,6 +127,16 @@ def main():
 
     P = int(args.packets)
     total_per_step = P * world
+    if world > 1:
+        os.environ.setdefault("SKH_THREADS", str(max(1, (os.cpu_count() or 1) // world)))  # host setup threads per rank
+    if args.config == 4:
+        if args.ski != SKI or args.source != "sersic":
+            raise SystemExit("--config 4 selects its own ski file and source")
+        args.ski = os.path.join(ROOT, "tests", "ski", "cfg4.ski")
+        sphdir = tempfile.mkdtemp(prefix=f"bench_sph_r{rank}_")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_sph.py"), "--n", "1000000", "--seed", "1",
+                               os.path.join(sphdir, "cfg4_sph.txt")])
+        os.environ["SKH_INPUT_PATH"] = sphdir
     # every rank sets up the same scene (replica of grid, densities, tables); numPackets = packets of one step over
     # all ranks, so that the per-packet luminosity is that of the whole segment
     ski_path = args.ski
@@ -192,14 +209,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: " + ("Sersic" if args.source == "sersic" else "uniform-box")
-                                   + " source, 953688-cell PolicyTreeSpatialGrid octree "
-                                   "(exp-disk dust, tau_z=1), 0.55 micron, forced scattering, peel-off to one "
+            "config": {"workload": ("BASELINE configs[1]: " + ("Sersic" if args.source == "sersic" else "uniform-box")
+                                    + " source, 953688-cell PolicyTreeSpatialGrid octree (exp-disk dust, tau_z=1)"
+                                    if args.config == 2 else
+                                    "BASELINE configs[3]: Sersic source, dust imported from 10^6 smoothed particles "
+                                    "(tools/make_sph.py --n 1000000 --seed 1), 985979-cell density-policy octree")
+                                   + ", 0.55 micron, forced scattering, peel-off to one "
                                    "FullInstrument 512^2 (components + statistics), " + os.path.relpath(args.ski, ROOT),
-                       "packets_per_step_per_gpu": P, "cells": 953688 if args.ski == SKI else None,
+                       "packets_per_step_per_gpu": P,
+                       "cells": 953688 if args.ski == SKI else 985979 if args.config == 4 else None,
                        "parallelism": f"history-range x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(P) if args.ski == SKI else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(P) if (args.ski == SKI and args.source == "sersic") else None,
                          "kernel": "walkKernel<octree>: all launches of one step, overlapped on the slot groups' streams "
                                    "(denominator: segment_ms)",
                          "kernel_ms": mean_ms, "walk_kernel_ms_sum": walk_ms_sum,
@@ -211,7 +232,7 @@ def main():
                          "algorithmic_bytes_per_packet": bytes_per_launch / P},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.ski if args.source == "sersic" else ski_path, os.environ.get("SKH_INPUT_PATH"))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
