@@ -100,8 +100,9 @@ def main():
     ap.add_argument("--source", choices=["sersic", "uniform"], default="sersic",
                     help="sersic: cfg2.ski as is (the headline workload); uniform: the same scene with the Sersic source "
                          "replaced by a UniformBoxGeometry source of +-10 x +-10 x +-1 kpc (north_star's second source)")
-    ap.add_argument("--config", type=int, choices=[2, 4], default=2,
-                    help="2: BASELINE configs[1] (the headline workload, tests/ski/cfg2.ski); 4: BASELINE configs[3], the same "
+    ap.add_argument("--config", type=int, choices=[2, 3, 4], default=2,
+                    help="2: BASELINE configs[1] (the headline workload, tests/ski/cfg2.ski); 3: BASELINE configs[2], the same scene "
+                         "panchromatic with a 50-bin wavelength grid (tests/ski/cfg3.ski); 4: BASELINE configs[3], the same "
                          "Sersic source in dust imported from 10^6 smoothed particles (tests/ski/cfg4.ski; the particle file "
                          "is regenerated by tools/make_sph.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -129,6 +130,10 @@ def main():
     total_per_step = P * world
     if world > 1:
         os.environ.setdefault("SKH_THREADS", str(max(1, (os.cpu_count() or 1) // world)))  # host setup threads per rank
+    if args.config == 3:
+        if args.ski != SKI or args.source != "sersic":
+            raise SystemExit("--config 3 selects its own ski file and source")
+        args.ski = os.path.join(ROOT, "tests", "ski", "cfg3.ski")
     if args.config == 4:
         if args.ski != SKI or args.source != "sersic":
             raise SystemExit("--config 4 selects its own ski file and source")
@@ -212,12 +217,15 @@ def main():
             "config": {"workload": ("BASELINE configs[1]: " + ("Sersic" if args.source == "sersic" else "uniform-box")
                                     + " source, 953688-cell PolicyTreeSpatialGrid octree (exp-disk dust, tau_z=1)"
                                     if args.config == 2 else
+                                    "BASELINE configs[2]: Sersic source, 953688-cell octree, panchromatic 0.1-10 micron, 50-bin "
+                                    "wavelength grid, tabulated dust mix (2102-point opacity table)"
+                                    if args.config == 3 else
                                     "BASELINE configs[3]: Sersic source, dust imported from 10^6 smoothed particles "
                                     "(tools/make_sph.py --n 1000000 --seed 1), 985979-cell density-policy octree")
-                                   + ", 0.55 micron, forced scattering, peel-off to one "
+                                   + (", 0.55 micron" if args.config != 3 else "") + ", forced scattering, peel-off to one "
                                    "FullInstrument 512^2 (components + statistics), " + os.path.relpath(args.ski, ROOT),
                        "packets_per_step_per_gpu": P,
-                       "cells": 953688 if args.ski == SKI else 985979 if args.config == 4 else None,
+                       "cells": 953688 if (args.ski == SKI or args.config == 3) else 985979 if args.config == 4 else None,
                        "parallelism": f"history-range x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(P) if (args.ski == SKI and args.source == "sersic") else None,

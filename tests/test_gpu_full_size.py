@@ -76,3 +76,33 @@ def test_full_size_conservation_and_linearity(full):
     eng.run_primary(N // 2, N - N // 2, 2024)
     halves = eng.download()
     assert np.allclose(whole, halves, rtol=1e-10, atol=1e-14 * np.abs(whole).max())
+
+
+def test_config3_full_size_panchromatic():
+    """BASELINE configs[2] at full size (tests/ski/cfg3.ski: the 953 688-cell octree, 50 wavelength bins, 512^2 pixels,
+    839 MB of detector arrays): every history lands in exactly one wavelength bin of the SED statistics, extinction only
+    removes flux in every bin, every bin receives packets, and a segment split in two accumulates to the same arrays"""
+    from skirt9_amd.engine import Engine
+    n = 200000
+    sim = Simulation(ski("cfg3.ski"), num_packets=n).setup()
+    eng = Engine(sim.scene, 0)
+    lay = sim.layout(0)
+    assert lay.num_lambda == 50 and lay.npix == 512 * 512
+    eng.run_primary(0, n, 77)
+    whole = eng.download()
+    c = eng.counters()
+    assert c["histories"] == n and c["stat_overflows"] == 0
+    nl = lay.num_lambda
+    sed = whole[lay.sed_offset:lay.sed_offset + lay.num_components * nl].reshape(lay.num_components, nl)
+    wsed = whole[lay.wsed_offset:lay.wsed_offset + 5 * nl].reshape(5, nl)
+    assert wsed[0].sum() == n
+    assert np.all(wsed[0] > 0)                       # the wavelength bias spreads packets over all 50 bins
+    assert np.all(sed[1] <= sed[0]) and np.all(sed[0] > 0)
+    # the dust is more opaque in the blue: the attenuated fraction falls with wavelength
+    frac = sed[1] / sed[0]
+    assert frac[:10].mean() < frac[-10:].mean()
+    eng.clear()
+    eng.run_primary(0, n // 2, 77)
+    eng.run_primary(n // 2, n - n // 2, 77)
+    halves = eng.download()
+    assert np.allclose(whole, halves, rtol=1e-10, atol=1e-14 * np.abs(whole).max())
