@@ -220,10 +220,10 @@ namespace skh
         }
     }
 
-    std::vector<Array> readColumnFile(const std::string& path, const std::vector<ColumnSpec>& columns)
+    std::vector<Array> readColumnFile(const std::string& path, const std::vector<ColumnSpec>& columns, const std::string& description)
     {
         std::ifstream in(path);
-        if (!in) throw std::runtime_error("Could not open the smoothed particles text file " + path);
+        if (!in) throw std::runtime_error("Could not open the " + description + " text file " + path);
         // ---- header: "# column N: description (unit)" lines (TextInFile.cpp:16-47,87-101); other '#' lines are comments
         struct FileColumn
         {

@@ -92,7 +92,8 @@ namespace skh
     {
         std::string description, quantity, defaultUnit;
     };
-    std::vector<Array> readColumnFile(const std::string& path, const std::vector<ColumnSpec>& columns);
+    std::vector<Array> readColumnFile(const std::string& path, const std::vector<ColumnSpec>& columns,
+                                      const std::string& description = "smoothed particles");
 }
 
 #endif

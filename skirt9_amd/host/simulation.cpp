@@ -271,13 +271,35 @@ namespace skh
             unsupported("a medium with a magnetic field");
         const XmlElement* mm = med.item("materialMix");
         if (!mm) throw std::runtime_error("ski: " + med.name + " lacks a material mix");
-        if (mm->name != "MeanListDustMix") unsupported("material mix " + mm->name);
+        if (mm->name != "MeanListDustMix" && mm->name != "MeanFileDustMix") unsupported("material mix " + mm->name);
         auto mix = std::make_unique<DustMix>();
         mix->typeName = mm->name;
-        mix->inLambda = rd.list(*mm, "wavelengths", "wavelength", "");
-        mix->inKappaExt = rd.list(*mm, "extinctionCoefficients", "masscoefficient", "");
-        mix->inAlbedo = rd.list(*mm, "albedos", "", "");
-        mix->inAsymmpar = rd.list(*mm, "asymmetryParameters", "", "");
+        if (mm->name == "MeanListDustMix")
+        {
+            mix->inLambda = rd.list(*mm, "wavelengths", "wavelength", "");
+            mix->inKappaExt = rd.list(*mm, "extinctionCoefficients", "masscoefficient", "");
+            mix->inAlbedo = rd.list(*mm, "albedos", "", "");
+            mix->inAsymmpar = rd.list(*mm, "asymmetryParameters", "", "");
+        }
+        else
+        {
+            // MeanFileDustMix.cpp:11-22: four columns of a text file (wavelength, kappa_ext, albedo, g)
+            std::string filename = mm->attr("filename", "");
+            if (filename.empty()) throw std::runtime_error("ski: MeanFileDustMix lacks a filename");
+            std::string path = (filename[0] == '/') ? filename : _inputPath + "/" + filename;
+            auto rows = readColumnFile(path, {{"wavelength", "wavelength", "micron"},
+                                              {"extinction mass coefficient", "masscoefficient", "m2/kg"},
+                                              {"scattering albedo", "", ""},
+                                              {"scattering asymmetry parameter", "", ""}},
+                                       "optical dust properties");
+            for (const Array& row : rows)
+            {
+                mix->inLambda.push_back(row[0]);
+                mix->inKappaExt.push_back(row[1]);
+                mix->inAlbedo.push_back(row[2]);
+                mix->inAsymmpar.push_back(row[3]);
+            }
+        }
         if (med.name == "GeometricMedium")
         {
             auto gm = std::make_unique<GeometricMedium>();

@@ -10,6 +10,7 @@ Fixtures:
   cfg2small_*  reduced config 2 (tests/ski/cfg2small.ski): 2x10^4 packets -> FITS/SED/statistics files
   cfg3small_*  reduced config 3 (tests/ski/cfg3small.ski): panchromatic, four instruments, 2x10^4 packets -> files
   cfg1nf_*     non-forced scattering variant of config 1 (tests/ski/cfg1nf.ski): 2x10^5 packets -> files
+  cfg1file_*   config 1 with MeanFileDustMix (tests/ski/cfg1file.ski + cfg1file_dust.txt): 10^5 packets -> files
   cfg4small_*  reduced config 4 (tests/ski/cfg4small.ski): dust imported from 3000 smoothed particles
                (tests/ski/cfg4small_sph.txt, made by tools/make_sph.py), 2x10^4 packets -> files, rays, cells
   *_rays.txt / *_rays_ref.txt   fixed rays and the reference's (m, ds) sequences (C99 hex floats)
@@ -49,7 +50,7 @@ def main():
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
     for name, scale in (("cfg1", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg3small", None), ("cfg1nf", None),
-                        ("cfg4small", 4000 * 3.08567758e16)):
+                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         ski = os.path.join(ROOT, "tests", "ski", name + ".ski")

@@ -210,3 +210,22 @@ def test_missing_particle_file_fails_loudly(tmp_path):
     (tmp_path / "m.ski").write_text(text)
     with pytest.raises(Exception, match="Could not open"):
         Simulation(str(tmp_path / "m.ski")).setup()
+
+
+def test_mean_file_dust_mix_equals_listed_values(tmp_path):
+    """MeanFileDustMix (MeanFileDustMix.cpp:11-22): the same four columns in a text file -- here in descending wavelength
+    order and cgs units -- give the dust tables that MeanListDustMix builds from the equivalent attribute lists"""
+    sim_file = Simulation(ski("cfg1file.ski")).setup()
+    text = open(ski("cfg1file.ski")).read().replace(
+        '<MeanFileDustMix filename="cfg1file_dust.txt"/>',
+        '<MeanListDustMix wavelengths="0.1 micron, 0.55 micron, 2.2 micron, 10 micron" '
+        'extinctionCoefficients="9000 m2/kg, 3000 m2/kg, 600 m2/kg, 60 m2/kg" albedos="0.4, 0.6, 0.45, 0.1" '
+        'asymmetryParameters="0.6, 0.5, 0.25, 0.05"/>')
+    (tmp_path / "l.ski").write_text(text)
+    sim_list = Simulation(str(tmp_path / "l.ski")).setup()
+    a, b = scene_head(sim_file).medium, scene_head(sim_list).medium
+    assert a.num_lambda == b.num_lambda
+    for field in ("lambda_border", "sigma_ext", "sigma_sca", "asymmpar"):
+        x = np.ctypeslib.as_array(getattr(a, field), shape=(a.num_lambda,))
+        y = np.ctypeslib.as_array(getattr(b, field), shape=(b.num_lambda,))
+        assert np.allclose(x, y, rtol=1e-14, atol=0), field
