@@ -17,6 +17,11 @@
  *                        ProcessManager::sumToRoot (SKIRT/mpi/ProcessManager.cpp:223-255) as ONE RCCL reduce
  *   pmc_trace_ray     <- PathSegmentGenerator::start()/next() (TreeSpatialGrid.cpp:132-217,
  *                        CartesianSpatialGrid.cpp:87-163): the (m, ds) sequence of one ray, for the bit-exact check
+ *   pmc_download_radiation_field <- the primary radiation field table MediumSystem::_rf1 that
+ *                        MonteCarloSimulation::storeRadiationField fills (MonteCarloSimulation.cpp:638-692,
+ *                        MediumSystem.cpp:1294-1300) and MediumSystem::meanIntensity reads (:1370-1380);
+ *   pmc_radiation_field_device <- same table as a device pointer, for the counterpart of
+ *                        MediumSystem::communicateRadiationField (MediumSystem.cpp:1304-1313: sumToAll) as one RCCL all-reduce
  *   pmc_counters      <- no reference counterpart: counted cell visits / detector updates for the roofline
  *
  * Conventions: plain C, no exceptions cross the boundary; every function returns PMC_OK (0) or a negative
@@ -35,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 2
+#define PMC_ABI_VERSION 3
 
 enum { PMC_OK = 0, PMC_ERR_INVALID = -1, PMC_ERR_UNSUPPORTED = -2, PMC_ERR_DEVICE = -3, PMC_ERR_NOMEM = -4 };
 
@@ -178,6 +183,21 @@ typedef struct pmc_frame_layout
     int64_t end_offset;
 } pmc_frame_layout;
 
+/* ---------------------------------------------------------------- radiation field ---- */
+
+/* RadiationFieldOptions::storeRadiationField (forced scattering only, Configuration.cpp:476-482): every segment of every
+   forced-scattering path adds  L * lnmean(e^-tau0, e^-tau1) * ds  to rf[m * num_lambda + ell], with ell the bin of the
+   packet's wavelength in the radiation field wavelength grid (MonteCarloSimulation.cpp:641-662; constant perceived
+   wavelength, i.e. no kinematics).  Bin lookup as for an instrument grid: ell = ellv[upper_bound(border, lambda)]. */
+typedef struct pmc_radiation_field
+{
+    int32_t        store;         /* 0: off (no table is allocated) */
+    int32_t        num_lambda;    /* bins of Configuration::radiationFieldWLG() */
+    int32_t        num_border;
+    const double*  border;
+    const int32_t* ellv;          /* num_border + 1 */
+} pmc_radiation_field;
+
 typedef struct pmc_scene
 {
     int32_t abi_version;            /* PMC_ABI_VERSION */
@@ -187,6 +207,7 @@ typedef struct pmc_scene
     pmc_source  source;
     int32_t     num_instruments;
     const pmc_instrument* instruments;
+    pmc_radiation_field radiation_field;
 } pmc_scene;
 
 /* counted work, accumulated over all pmc_run_primary calls since create/reset (roofline inputs) */
@@ -227,6 +248,12 @@ int pmc_sync(pmc_ctx* ctx);
 int pmc_download(pmc_ctx* ctx, double* host_frames, int64_t num_doubles);
 double* pmc_frames_device(pmc_ctx* ctx);
 int64_t pmc_frames_size(pmc_ctx* ctx);
+/* Radiation field table rf[m * num_lambda + ell] (doubles, W m): size (0 if the scene does not store it), device
+   pointer, copy to the host, reset to zero.  Like the frames it is ACCUMULATED into by every pmc_run_primary. */
+int64_t pmc_radiation_field_size(pmc_ctx* ctx);
+double* pmc_radiation_field_device(pmc_ctx* ctx);
+int pmc_download_radiation_field(pmc_ctx* ctx, double* host_rf, int64_t num_doubles);
+int pmc_clear_radiation_field(pmc_ctx* ctx);
 /* milliseconds spent in the walk kernel (the dominant kernel) during the most recent pmc_run_primary, summed over
    its launches and measured with HIP events on the streams they run on (the launches of different slot groups
    overlap, so the sum can exceed the segment time reported by pmc_last_timing) */

@@ -481,6 +481,7 @@ namespace
         Rng& rng;
         double* frames;
         pmc_counter_values counters{};
+        double* radiationField{nullptr};  // rf[m * num_lambda + ell], or null: not stored
         std::unique_ptr<Generator> generator;
         std::vector<pmc_frame_layout> layouts;
         // per instrument contribution lists for the statistics (FluxRecorder.hpp:308-343)
@@ -640,6 +641,49 @@ namespace
                     counters.cell_visits++;
                 }
                 seg.tau = tau;
+            }
+        }
+
+        // ---- MonteCarloSimulation::storeRadiationField, constant perceived wavelength (MonteCarloSimulation.cpp:638-662)
+        //      with SpecialFunctions::lnmean (SpecialFunctions.cpp:860-880) and MediumSystem::storeRadiationField
+        //      (MediumSystem.cpp:1294-1300): rf1(m, ell) += L * lnmean(extEnd, extBeg) * ds
+        static double lnmean(double x1, double x2, double lnx1, double lnx2)
+        {
+            if (x1 > x2)
+            {
+                std::swap(x1, x2);
+                std::swap(lnx1, lnx2);
+            }
+            if (x1 <= 0) return 0.;
+            double x = x2 / x1 - 1.;
+            if (x < 1e-3)
+                return x1
+                       / (1. - 1. / 2. * x + 1. / 3. * x * x - 1. / 4. * x * x * x + 1. / 5. * x * x * x * x
+                          - 1. / 6. * x * x * x * x * x);
+            return (x2 - x1) / (lnx2 - lnx1);
+        }
+        void storeRadiationField(const Packet& pp)
+        {
+            const pmc_radiation_field& R = sc.radiation_field;
+            // DisjointWavelengthGrid::bin (DisjointWavelengthGrid.cpp:334-345)
+            int ell = R.ellv[std::upper_bound(R.border, R.border + R.num_border, pp.lambda) - R.border];
+            if (ell < 0) return;
+            double luminosity = pp.luminosity();
+            double lnExtBeg = 0.;
+            double extBeg = 1.;
+            for (const auto& segment : pp.segments)
+            {
+                double lnExtEnd = -segment.tau;
+                double extEnd = exp(lnExtEnd);
+                int m = segment.m;
+                if (m >= 0)
+                {
+                    double extMean = lnmean(extEnd, extBeg, lnExtEnd, lnExtBeg);
+                    double Lds = luminosity * extMean * segment.ds;
+                    radiationField[static_cast<size_t>(m) * R.num_lambda + ell] += Lds;
+                }
+                lnExtBeg = lnExtEnd;
+                extBeg = extEnd;
             }
         }
 
@@ -1018,6 +1062,7 @@ namespace
                         while (true)
                         {
                             setExtinctionOpticalDepths(pp);
+                            if (radiationField) storeRadiationField(pp);
                             simulateForcedPropagation(pp);
                             if (pp.luminosity() <= 0 || (pp.luminosity() <= Lthreshold && pp.nscatt >= minScattEvents)) break;
                             peelOffScattering(pp, ppp);
@@ -1069,6 +1114,24 @@ int oracle_run_primary(const pmc_scene* scene, uint64_t first, uint64_t count, i
         rng.reset(new PhiloxRng(seed));
     LifeCycle cycle(*scene, *rng, frames);
     // the reference's contribution list starts with history index 0 and an empty list (FluxRecorder.hpp:335)
+    cycle.run(first, count);
+    cycle.flush();
+    if (counters) *counters = cycle.counters;
+    return PMC_OK;
+}
+
+// the same with the radiation field table rf[m * num_lambda + ell] (scene->radiation_field.store must be set)
+int oracle_run_primary_rf(const pmc_scene* scene, uint64_t first, uint64_t count, int rng_kind, uint64_t seed,
+                          uint64_t skip_draws, double* frames, double* rf, pmc_counter_values* counters)
+{
+    if (!scene || !frames || !rf || !scene->radiation_field.store) return PMC_ERR_INVALID;
+    std::unique_ptr<Rng> rng;
+    if (rng_kind == 0)
+        rng.reset(new MtRng(static_cast<int>(seed), skip_draws));
+    else
+        rng.reset(new PhiloxRng(seed));
+    LifeCycle cycle(*scene, *rng, frames);
+    cycle.radiationField = rf;
     cycle.run(first, count);
     cycle.flush();
     if (counters) *counters = cycle.counters;

@@ -23,7 +23,7 @@
 extern "C" hipError_t pmcUploadScene(int slot, const DevScene* scene, hipStream_t stream);
 extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds);
 extern "C" int pmcWalkBlocksPerCU(int gridKind, int block, size_t ldsBytes);
-extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int taskBase, int numTaskRecords, int taskCounter, uint64_t seed, int grid,
+extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int taskBase, int numTaskRecords, int taskCounter, uint64_t seed, int grid,
                                     int block, size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
                                           uint64_t seed, int maxBlocks, size_t ldsBytes, hipStream_t stream);
@@ -76,6 +76,7 @@ struct pmc_ctx
     std::vector<void*> slotAllocations;
     double* frames{nullptr};
     int64_t frameSize{0};
+    int64_t rfSize{0};  // doubles of the radiation field table (0: not stored)
     size_t walkLds{0}, transitionLds{0};
     int block{256};
     int grid{0};
@@ -305,6 +306,7 @@ namespace
         if ((rc = ctx->allocate<double>(size_t(n) * PMC_MAX_INSTRUMENTS, &A.ptau, false, &own))) return rc;
         if ((rc = ctx->allocate<int32_t>(size_t(n) * PMC_MAX_INSTRUMENTS, &A.ell, true, &own))) return rc;
         if ((rc = ctx->allocate<int32_t>(size_t(n) * PMC_MAX_INSTRUMENTS, &A.nstat, true, &own))) return rc;
+        if (ctx->dev.rf_store && (rc = ctx->allocate<int32_t>(n, &A.rfell, true, &own))) return rc;
         if (ctx->dev.any_stats)
         {
             size_t entries = size_t(ctx->dev.num_instruments) * PMC_STAT_CAP * size_t(n);
@@ -555,6 +557,23 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if (d.include_sed) sedDoubles += (d.num_components + (d.record_stats ? 5 : 0)) * d.num_lambda;
         if (d.record_stats) D.any_stats = 1;
     }
+    // ---- radiation field table
+    const pmc_radiation_field& RF = scene->radiation_field;
+    D.rf_store = RF.store ? 1 : 0;
+    ctx->rfSize = 0;
+    if (D.rf_store)
+    {
+        if (!scene->options.force_scattering)
+            return bail(fail(PMC_ERR_INVALID, "the radiation field can only be stored with forced scattering (Configuration.cpp:476-482)"));
+        if (RF.num_lambda < 1 || RF.num_border < 1 || !RF.border || !RF.ellv)
+            return bail(fail(PMC_ERR_INVALID, "radiation field wavelength grid is missing"));
+        D.rf_num_lambda = RF.num_lambda;
+        D.rf_num_border = RF.num_border;
+        if ((rc = ctx->upload(RF.border, RF.num_border, &D.rf_border))) return bail(rc);
+        if ((rc = ctx->upload(RF.ellv, RF.num_border + 1, &D.rf_ellv))) return bail(rc);
+        ctx->rfSize = int64_t(scene->grid.num_cells) * RF.num_lambda;
+        if ((rc = ctx->allocate<double>(size_t(ctx->rfSize), &D.rf, true))) return bail(rc);
+    }
     D.lds_sed_len = sedDoubles;
     transDoubles += sedDoubles;
     D.lds_hot_off = transDoubles;
@@ -697,7 +716,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         {
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(g), 0, sizeof(unsigned long long), sg));  // task cursor
             HIP_TRY(hipEventRecord(ctx->evA[g], sg));
-            HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, base[g], size[g], PMC_CTR_TASK(g), seed, ctx->grid, ctx->block, ctx->walkLds,
+            HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, D.rf_store, base[g], size[g], PMC_CTR_TASK(g), seed, ctx->grid, ctx->block, ctx->walkLds,
                                   sg));
             haveWalk[g] = true;
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
@@ -804,6 +823,36 @@ double* pmc_frames_device(pmc_ctx* ctx)
 int64_t pmc_frames_size(pmc_ctx* ctx)
 {
     return ctx ? ctx->frameSize : 0;
+}
+
+int64_t pmc_radiation_field_size(pmc_ctx* ctx)
+{
+    return ctx ? ctx->rfSize : 0;
+}
+
+double* pmc_radiation_field_device(pmc_ctx* ctx)
+{
+    return ctx ? ctx->dev.rf : nullptr;
+}
+
+int pmc_download_radiation_field(pmc_ctx* ctx, double* host_rf, int64_t num_doubles)
+{
+    if (!ctx || !host_rf) return fail(PMC_ERR_INVALID, "null argument");
+    if (!ctx->rfSize) return fail(PMC_ERR_INVALID, "the scene does not store the radiation field");
+    if (num_doubles != ctx->rfSize) return fail(PMC_ERR_INVALID, "radiation field size mismatch");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(host_rf, ctx->dev.rf, size_t(num_doubles) * sizeof(double), hipMemcpyDeviceToHost));
+    return PMC_OK;
+}
+
+int pmc_clear_radiation_field(pmc_ctx* ctx)
+{
+    if (!ctx) return fail(PMC_ERR_INVALID, "null context");
+    if (!ctx->rfSize) return PMC_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(ctx->dev.rf, 0, size_t(ctx->rfSize) * sizeof(double), ctx->stream));
+    return PMC_OK;
 }
 
 int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out)

@@ -90,6 +90,7 @@ struct SlotArrays
     int32_t* cellhint;                      // octree leaf that contains the position, or -1
     int32_t* ell;                           // [PMC_MAX_INSTRUMENTS][num_slots] wavelength bin per instrument
     int32_t* nstat;                         // [PMC_MAX_INSTRUMENTS][num_slots] length of the contribution list
+    int32_t* rfell;                         // wavelength bin in the radiation field grid, -1 outside (only if rf_store)
     // walk results
     double* ptau;                           // [PMC_MAX_INSTRUMENTS][num_slots] optical depth towards that observer (inf: the
                                             // contribution is zero)
@@ -182,6 +183,11 @@ struct DevScene
     int32_t num_instruments;
     DevInstrument inst[PMC_MAX_INSTRUMENTS];
     int32_t any_stats;
+    // ---- radiation field (MonteCarloSimulation::storeRadiationField): rf[m * rf_num_lambda + ell]
+    int32_t rf_store, rf_num_lambda, rf_num_border;
+    const double* rf_border;
+    const int32_t* rf_ellv;
+    double* rf;
     // ---- outputs and work state
     double* frames;
     unsigned long long* counters;  // [PMC_NUM_COUNTERS]: [0..6] pmc_counter_values, [8] next history offset,

@@ -176,8 +176,10 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
     {
         const void* kernel;
         size_t lds;
-    } all[] = {{reinterpret_cast<const void*>(&walkKernel<GRID_TREE>), walkLds},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_CART>), walkLds},
+    } all[] = {{reinterpret_cast<const void*>(&walkKernel<GRID_TREE, false>), walkLds},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, false>), walkLds},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_TREE, true>), walkLds},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, true>), walkLds},
                {reinterpret_cast<const void*>(&traceRayKernel<GRID_TREE>), walkLds},
                {reinterpret_cast<const void*>(&traceRayKernel<GRID_CART>), walkLds},
                {reinterpret_cast<const void*>(&transitionKernel<GRID_TREE>), transitionLds},
@@ -197,23 +199,21 @@ extern "C" int pmcWalkBlocksPerCU(int gridKind, int block, size_t ldsBytes)
     int n = 0;
     hipError_t e;
     if (gridKind == PMC_GRID_OCTREE)
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_TREE>), block, ldsBytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_TREE, false>), block, ldsBytes);
     else
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_CART>), block, ldsBytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_CART, false>), block, ldsBytes);
     return e == hipSuccess ? n : 0;
 }
 
 // walks of the task records [taskBase, taskBase + numTaskRecords) of one slot group; taskCounter = index of the
 // group's (zeroed) cursor
-extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int taskBase, int numTaskRecords, int taskCounter, uint64_t seed, int grid,
-                                    int block, size_t ldsBytes, hipStream_t stream)
+extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int taskBase, int numTaskRecords, int taskCounter,
+                                    uint64_t seed, int grid, int block, size_t ldsBytes, hipStream_t stream)
 {
-    if (gridKind == PMC_GRID_OCTREE)
-        hipLaunchKernelGGL(walkKernel<GRID_TREE>, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter,
-                           seed);
-    else
-        hipLaunchKernelGGL(walkKernel<GRID_CART>, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter,
-                           seed);
+    // (the radiation-field flavour is a separate instantiation: the plain photon loop pays nothing for it)
+    auto kernel = gridKind == PMC_GRID_OCTREE ? (storeRf ? walkKernel<GRID_TREE, true> : walkKernel<GRID_TREE, false>)
+                                              : (storeRf ? walkKernel<GRID_CART, true> : walkKernel<GRID_CART, false>);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter, seed);
     return hipGetLastError();
 }
 

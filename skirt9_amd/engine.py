@@ -18,7 +18,8 @@ _LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 SYMBOLS = ["pmc_abi_version", "pmc_last_error", "pmc_frame_layout_of", "pmc_create", "pmc_destroy", "pmc_bind_frames",
            "pmc_clear_frames", "pmc_run_primary", "pmc_sync", "pmc_download", "pmc_frames_device", "pmc_frames_size",
            "pmc_last_kernel_ms", "pmc_counters", "pmc_reset_counters", "pmc_trace_ray", "pmc_set_launch",
-           "pmc_set_num_slots", "pmc_last_timing"]
+           "pmc_set_num_slots", "pmc_last_timing", "pmc_radiation_field_size", "pmc_radiation_field_device",
+           "pmc_download_radiation_field", "pmc_clear_radiation_field"]
 
 _lib = None
 
@@ -54,6 +55,12 @@ def lib():
         L.pmc_set_num_slots.argtypes = [C.c_void_p, C.c_int64]
         L.pmc_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                       C.POINTER(C.c_int32)]
+        L.pmc_radiation_field_size.restype = C.c_int64
+        L.pmc_radiation_field_size.argtypes = [C.c_void_p]
+        L.pmc_radiation_field_device.restype = C.c_void_p
+        L.pmc_radiation_field_device.argtypes = [C.c_void_p]
+        L.pmc_download_radiation_field.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.pmc_clear_radiation_field.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -127,6 +134,24 @@ class Engine:
         out = np.empty(self.frame_size, dtype=np.float64)
         _check(lib().pmc_download(self._h, out.ctypes.data_as(C.c_void_p), out.size))
         return out
+
+    @property
+    def radiation_field_size(self):
+        return int(lib().pmc_radiation_field_size(self._h))
+
+    @property
+    def radiation_field_device_ptr(self):
+        """device address of the radiation field table (for an RCCL all-reduce across ranks)"""
+        return int(lib().pmc_radiation_field_device(self._h) or 0)
+
+    def download_radiation_field(self):
+        """rf[m * nbins + ell] accumulated by the segments run so far (MediumSystem::_rf1)"""
+        out = np.empty(self.radiation_field_size, dtype=np.float64)
+        _check(lib().pmc_download_radiation_field(self._h, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def clear_radiation_field(self):
+        _check(lib().pmc_clear_radiation_field(self._h))
 
     def counters(self):
         c = CounterValues()

@@ -61,6 +61,9 @@ def lib():
         L.skh_frame_layout.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FrameLayout)]
         L.skh_write.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
         L.skh_summary.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+        L.skh_radiation_field_size.restype = C.c_int64
+        L.skh_radiation_field_size.argtypes = [C.c_void_p]
+        L.skh_write_radiation_field.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
         _lib = L
     return _lib
 
@@ -131,6 +134,20 @@ class Simulation:
         if lib().skh_frame_layout(self._h, instrument, C.byref(out)) != 0:
             raise IndexError(instrument)
         return out
+
+    @property
+    def radiation_field_size(self):
+        """doubles of the radiation field table rf[m * nbins + ell]; 0 if the simulation does not store it"""
+        return int(lib().skh_radiation_field_size(self._h))
+
+    def write_radiation_field(self, rf, outdir):
+        """write the RadiationFieldProbe files (<prefix>_<probe>_J.dat) from the table the engine accumulated"""
+        import numpy as np
+        data = np.ascontiguousarray(rf, dtype=np.float64)
+        assert data.size == self.radiation_field_size
+        os.makedirs(outdir, exist_ok=True)
+        if lib().skh_write_radiation_field(self._h, data.ctypes.data_as(C.c_void_p), os.fsencode(outdir)) != 0:
+            raise RuntimeError(lib().skh_last_error().decode())
 
     def summary(self):
         buf = C.create_string_buffer(2048)

@@ -150,6 +150,27 @@ int skh_write(const skh_simulation* h, double* frames, const char* outdir)
     }
 }
 
+// number of doubles of the radiation field table (0: the simulation does not store it)
+int64_t skh_radiation_field_size(const skh_simulation* h)
+{
+    return h && h->sim ? h->sim->radiationFieldSize() : 0;
+}
+
+// writes the RadiationFieldProbe files from the table rf[m * nbins + ell]
+int skh_write_radiation_field(const skh_simulation* h, const double* rf, const char* outdir)
+{
+    try
+    {
+        if (!h || !h->sim || !rf || !outdir) throw std::runtime_error("invalid argument");
+        h->sim->writeRadiationField(rf, outdir);
+        return 0;
+    }
+    catch (const std::exception& e)
+    {
+        return fail(e);
+    }
+}
+
 int skh_summary(const skh_simulation* h, char* buffer, int32_t capacity)
 {
     std::string s = h->sim->summary();

@@ -40,6 +40,19 @@ namespace skh
         if (fluxStyle == "Wavelength") return out("wavelengthfluxdensity", Flambda);
         return out("frequencyfluxdensity", lambda * lambda * Flambda / constants::c);
     }
+    std::string OutputUnits::smeanintensity() const
+    {
+        if (fluxStyle == "Neutral") return "lambda*J_lambda";
+        if (fluxStyle == "Wavelength") return "J_lambda";
+        return "J_nu";
+    }
+    std::string OutputUnits::umeanintensity() const { return unit(stylePrefix(fluxStyle) + "meanintensity"); }
+    double OutputUnits::omeanintensity(double lambda, double Jlambda) const
+    {
+        if (fluxStyle == "Neutral") return out("neutralmeanintensity", lambda * Jlambda);
+        if (fluxStyle == "Wavelength") return out("wavelengthmeanintensity", Jlambda);
+        return out("frequencymeanintensity", lambda * lambda * Jlambda / constants::c);
+    }
     double OutputUnits::osurfacebrightness(double lambda, double flambda) const
     {
         if (fluxStyle == "Neutral") return out("neutralsurfacebrightness", lambda * flambda);

@@ -34,6 +34,9 @@ namespace skh
         double ofluxdensity(double lambda, double Flambda) const;
         std::string usurfacebrightness() const;
         double osurfacebrightness(double lambda, double flambda) const;
+        std::string smeanintensity() const;  // Units.cpp:613-651
+        std::string umeanintensity() const;
+        double omeanintensity(double lambda, double Jlambda) const;
     };
 
     // ---------------------------------------------------------------- geometries

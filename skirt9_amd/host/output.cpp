@@ -246,6 +246,64 @@ namespace skh
         };
     }
 
+    int64_t Simulation::radiationFieldSize() const
+    {
+        return _storeRadiationField ? static_cast<int64_t>(_grid->numCells()) * _rfGrid->numBins() : 0;
+    }
+
+    // RadiationFieldProbe::probe with a PerCellForm (RadiationFieldProbe.cpp:27-78, PerCellForm.cpp:14-32): the mean
+    // intensity J = rf / (4 pi V dlambda) (MediumSystem::meanIntensity, MediumSystem.cpp:1370-1380) of every cell, one
+    // column per wavelength bin, in output units
+    std::vector<std::string> Simulation::writeRadiationField(const double* rf, const std::string& outdir) const
+    {
+        std::vector<std::string> files;
+        if (!_storeRadiationField) return files;
+        std::string base = outdir;
+        if (!base.empty() && base.back() != '/') base += '/';
+        base += _prefix + "_";
+        const WavelengthGrid& wlg = *_rfGrid;
+        const int nbins = wlg.numBins();
+        // Units::rwavelength(): the output runs over decreasing wavelength unless wavelengths are written as such
+        const bool reverse = _units.wavelengthStyle != "Wavelength";
+        std::vector<int> order(nbins);
+        for (int i = 0; i != nbins; ++i) order[i] = reverse ? nbins - 1 - i : i;
+        Array conv(nbins);
+        for (int i = 0; i != nbins; ++i) conv[i] = _units.omeanintensity(wlg.wavelength(order[i]), 1.);
+        for (const std::string& name : _rfProbeNames)
+        {
+            std::string path = base + name + "_J.dat";
+            std::ofstream out(path);
+            if (!out) throw std::runtime_error("Could not open output file " + path);
+            out << "# Mean intensity per spatial cell" << std::endl;
+            out << "# column 1: spatial cell index (1)" << std::endl;
+            for (int i = 0; i != nbins; ++i)
+            {
+                char buf[40];
+                snprintf(buf, sizeof(buf), "%1.6g", _units.owavelength(wlg.wavelength(order[i])));
+                out << "# column " << (i + 2) << ": " << _units.smeanintensity() << " at " << _units.swavelength() << " = " << buf
+                    << " " << _units.uwavelength() << " (" << _units.umeanintensity() << ")" << std::endl;
+            }
+            const int numCells = _grid->numCells();
+            for (int m = 0; m != numCells; ++m)
+            {
+                // MediumSystem::meanIntensity
+                double factor = 1. / (4. * M_PI * _grid->cellBox(m).volume());
+                std::string line = std::to_string(m);
+                for (int i = 0; i != nbins; ++i)
+                {
+                    int ell = order[i];
+                    double J = rf[static_cast<size_t>(m) * nbins + ell] * factor / wlg.effectiveWidth(ell);
+                    char buf[40];
+                    snprintf(buf, sizeof(buf), " %1.9e", conv[i] * J);
+                    line += buf;
+                }
+                out << line << std::endl;
+            }
+            files.push_back(path);
+        }
+        return files;
+    }
+
     std::vector<std::string> Simulation::write(double* frames, const std::string& outdir) const
     {
         std::vector<std::string> files;

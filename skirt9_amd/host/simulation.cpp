@@ -259,7 +259,19 @@ namespace skh
             _options.path_length_bias = rd.number(*po, "pathLengthBias", _options.force_scattering ? "0.5" : "0");
         }
         if (const XmlElement* rf = ms->item("radiationFieldOptions"))
-            if (rd.boolean(*rf, "storeRadiationField", false)) unsupported("storeRadiationField");
+            if (rd.boolean(*rf, "storeRadiationField", false))
+            {
+                // Configuration.cpp:244-250,476-482: the field is stored on the oligochromatic grid, or on the configured
+                // radiationFieldWLG; storing it requires forced scattering (the reference switches it on with a warning)
+                _storeRadiationField = true;
+                if (!_options.force_scattering) unsupported("storeRadiationField without forceScattering");
+                if (!_oligo)
+                {
+                    const XmlElement* wg = rf->item("radiationFieldWLG");
+                    if (!wg) throw std::runtime_error("ski: RadiationFieldOptions lacks a radiationFieldWLG");
+                    _rfGridOwn = makeWavelengthGrid(*wg, rd);
+                }
+            }
         if (const XmlElement* so = ms->item("samplingOptions")) _numDensitySamples = rd.integer(*so, "numDensitySamples", 100);
         auto media = ms->items("media");
         if (media.size() != 1) unsupported("a medium system with " + std::to_string(media.size()) + " media");
@@ -416,6 +428,19 @@ namespace skh
             _instruments.push_back(std::move(ins));
         }
         if (_instruments.empty()) unsupported("a simulation without instruments");
+
+        // ---- probes: the radiation field per cell (RadiationFieldProbe + PerCellForm); nothing else is on this path
+        if (const XmlElement* ps = sim.item("probeSystem"))
+            for (const XmlElement* pe : ps->items("probes"))
+            {
+                if (pe->name != "RadiationFieldProbe") unsupported("probe " + pe->name);
+                const XmlElement* form = pe->item("form");
+                if (!form || form->name != "PerCellForm") unsupported("probe form " + (form ? form->name : std::string("(none)")));
+                if (rd.boolean(*pe, "writeWavelengthGrid", false)) unsupported("RadiationFieldProbe writeWavelengthGrid");
+                std::string after = pe->attr("probeAfter", "Run");
+                if (after != "Run" && after != "Primary") unsupported("RadiationFieldProbe probeAfter " + after);
+                _rfProbeNames.push_back(pe->attr("probeName", ""));
+            }
     }
 
     // ================================================================ setup
@@ -439,6 +464,8 @@ namespace skh
             sourceMax = _ssMaxWavelength;
         }
         const WavelengthGrid* defaultGrid = _oligo ? _oligoGrid.get() : _defaultGrid.get();
+        if (_storeRadiationField) _rfGrid = _oligo ? _oligoGrid.get() : _rfGridOwn.get();
+
 
         // instruments: grid in effect (Configuration::wavelengthGrid, Configuration.cpp:666-671) and observer sharing
         // (DistantInstrument::determineSameObserverAsPreceding, DistantInstrument.cpp:55-63)
@@ -467,6 +494,7 @@ namespace skh
             for (double w : g->lambdav) simWavelengths.insert(w);
         };
         if (defaultGrid) addGrid(defaultGrid);
+        if (_rfGrid && !_oligo) addGrid(_rfGrid);  // Configuration.cpp:576-579,644
         for (auto& ins : _instruments)
             if (ins.ownGrid) addGrid(ins.ownGrid.get());
         // MaterialWavelengthRangeInterface items: the normalisation wavelength and the tree policy wavelength
@@ -727,6 +755,16 @@ namespace skh
         }
         _scene.num_instruments = static_cast<int32_t>(_pmcInstruments.size());
         _scene.instruments = _pmcInstruments.data();
+        _scene.radiation_field = pmc_radiation_field{};
+        if (_storeRadiationField)
+        {
+            pmc_radiation_field& R = _scene.radiation_field;
+            R.store = 1;
+            R.num_lambda = _rfGrid->numBins();
+            R.num_border = static_cast<int32_t>(_rfGrid->borderv.size());
+            R.border = _rfGrid->borderv.data();
+            R.ellv = _rfGrid->ellv.data();
+        }
 
         _layouts.resize(_instruments.size());
         for (size_t i = 0; i < _instruments.size(); ++i) _frameSize = pmc_layout_compute(&_scene, static_cast<int32_t>(i), &_layouts[i]);

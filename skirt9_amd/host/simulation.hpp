@@ -41,6 +41,12 @@ namespace skh
         // detector arrays in the pmc_frame_layout order and is calibrated IN PLACE.  Returns the files written.
         std::vector<std::string> write(double* frames, const std::string& outdir) const;
 
+        // Radiation field (RadiationFieldOptions::storeRadiationField): number of doubles of the table rf[m * nbins + ell]
+        // that pmc_download_radiation_field fills (0 if not stored), and the RadiationFieldProbe / PerCellForm output
+        // files "<prefix>_<probe>_J.dat" (RadiationFieldProbe.cpp:27-78, PerCellForm.cpp:14-32) written from it
+        int64_t radiationFieldSize() const;
+        std::vector<std::string> writeRadiationField(const double* rf, const std::string& outdir) const;
+
         // human-readable summary (grid size, tables, ...) for logs and tests
         std::string summary() const;
 
@@ -77,6 +83,11 @@ namespace skh
         std::unique_ptr<SpatialGrid> _grid;
         std::vector<char> _topology;
         Array _density;
+        // radiation field
+        bool _storeRadiationField{false};
+        std::unique_ptr<WavelengthGrid> _rfGridOwn;       // radiationFieldWLG as configured (panchromatic)
+        const WavelengthGrid* _rfGrid{nullptr};           // Configuration::radiationFieldWLG()
+        std::vector<std::string> _rfProbeNames;           // RadiationFieldProbe items with a PerCellForm
         // instruments
         std::unique_ptr<WavelengthGrid> _defaultGrid;     // as configured in the ski (panchromatic)
         std::unique_ptr<WavelengthGrid> _oligoGrid;       // OligoWavelengthGrid

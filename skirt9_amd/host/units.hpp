@@ -103,17 +103,24 @@ namespace skh
             add("wavelengthsurfacebrightness", "W/m2/micron/sr", 1e6);
             add("wavelengthsurfacebrightness", "W/m2/micron/arcsec2", 1e6 / arcsec2);
             add("neutralfluxdensity", "W/m2", 1.);
+            add("neutralmeanintensity", "W/m2/sr", 1.);
+            add("wavelengthmeanintensity", "W/m3/sr", 1.);
+            add("wavelengthmeanintensity", "W/m2/micron/sr", 1e6);
+            add("frequencymeanintensity", "W/m2/Hz/sr", 1.);
+            add("frequencymeanintensity", "MJy/sr", 1e-20);
             add("neutralsurfacebrightness", "W/m2/sr", 1.);
             add("neutralsurfacebrightness", "W/m2/arcsec2", 1. / arcsec2);
 
             // default units per unit system (SkirtUnitDef.cpp:556-764)
-            def("SIUnits", {{"length", "m"}, {"distance", "m"}, {"wavelength", "m"}, {"velocity", "m/s"},
+            def("SIUnits", {{"neutralmeanintensity", "W/m2/sr"}, {"wavelengthmeanintensity", "W/m3/sr"},
+                            {"frequencymeanintensity", "W/m2/Hz/sr"}, {"length", "m"}, {"distance", "m"}, {"wavelength", "m"}, {"velocity", "m/s"},
                             {"masscoefficient", "m2/kg"}, {"mass", "kg"}, {"temperature", "K"}, {"magneticfield", "T"},
                             {"bolluminosity", "W"}, {"angle", "rad"}, {"posangle", "rad"},
                             {"frequencyfluxdensity", "W/m2/Hz"}, {"frequencysurfacebrightness", "W/m2/Hz/sr"},
                             {"wavelengthfluxdensity", "W/m3"}, {"wavelengthsurfacebrightness", "W/m3/sr"},
                             {"neutralfluxdensity", "W/m2"}, {"neutralsurfacebrightness", "W/m2/sr"}});
-            def("StellarUnits", {{"length", "AU"}, {"distance", "pc"}, {"wavelength", "micron"}, {"velocity", "km/s"},
+            def("StellarUnits", {{"neutralmeanintensity", "W/m2/sr"}, {"wavelengthmeanintensity", "W/m2/micron/sr"},
+                                 {"frequencymeanintensity", "W/m2/Hz/sr"}, {"length", "AU"}, {"distance", "pc"}, {"wavelength", "micron"}, {"velocity", "km/s"},
                                  {"masscoefficient", "m2/kg"}, {"mass", "Msun"}, {"temperature", "K"}, {"magneticfield", "uG"},
                                  {"bolluminosity", "Lsun"}, {"angle", "arcsec"}, {"posangle", "deg"},
                                  {"frequencyfluxdensity", "Jy"}, {"frequencysurfacebrightness", "MJy/sr"},
@@ -121,7 +128,9 @@ namespace skh
                                  {"wavelengthsurfacebrightness", "W/m2/micron/arcsec2"},
                                  {"neutralfluxdensity", "W/m2"}, {"neutralsurfacebrightness", "W/m2/arcsec2"}});
             def("ExtragalacticUnits",
-                {{"length", "pc"}, {"distance", "Mpc"}, {"wavelength", "micron"}, {"velocity", "km/s"},
+                {{"neutralmeanintensity", "W/m2/sr"}, {"wavelengthmeanintensity", "W/m2/micron/sr"},
+                 {"frequencymeanintensity", "W/m2/Hz/sr"},
+                 {"length", "pc"}, {"distance", "Mpc"}, {"wavelength", "micron"}, {"velocity", "km/s"},
                  {"masscoefficient", "m2/kg"}, {"mass", "Msun"}, {"temperature", "K"}, {"magneticfield", "uG"}, {"bolluminosity", "Lsun"},
                  {"angle", "arcsec"}, {"posangle", "deg"}, {"frequencyfluxdensity", "Jy"},
                  {"frequencysurfacebrightness", "MJy/sr"}, {"wavelengthfluxdensity", "W/m2/micron"},

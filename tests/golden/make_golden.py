@@ -11,6 +11,8 @@ Fixtures:
   cfg3small_*  reduced config 3 (tests/ski/cfg3small.ski): panchromatic, four instruments, 2x10^4 packets -> files
   cfg1nf_*     non-forced scattering variant of config 1 (tests/ski/cfg1nf.ski): 2x10^5 packets -> files
   cfg1file_*   config 1 with MeanFileDustMix (tests/ski/cfg1file.ski + cfg1file_dust.txt): 10^5 packets -> files
+  cfg1rf_*, cfg3rf_*   config 1 and reduced config 3 with storeRadiationField and a RadiationFieldProbe (PerCellForm):
+               the probe file <name>_rf_J.dat (gzip) and the SED files
   cfg4small_*  reduced config 4 (tests/ski/cfg4small.ski): dust imported from 3000 smoothed particles
                (tests/ski/cfg4small_sph.txt, made by tools/make_sph.py), 2x10^4 packets -> files, rays, cells
   *_rays.txt / *_rays_ref.txt   fixed rays and the reference's (m, ds) sequences (C99 hex floats)
@@ -50,7 +52,7 @@ def main():
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
     for name, scale in (("cfg1", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg3small", None), ("cfg1nf", None),
-                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None)):
+                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1rf", "rf"), ("cfg3rf", "rf")):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         ski = os.path.join(ROOT, "tests", "ski", name + ".ski")
@@ -60,6 +62,16 @@ def main():
                 if f.startswith(name) and f.endswith(".txt"):
                     shutil.copy(os.path.join(ROOT, "tests", "ski", f), tmp)
             subprocess.check_call([REF, "run", ski, "-t", "1", "-o", tmp], cwd=tmp, stdout=subprocess.DEVNULL)
+            if scale == "rf":
+                # radiation field variants of scenes above: keep the probe file (gzip) and the SEDs only
+                import gzip
+                for f in sorted(os.listdir(tmp)):
+                    if f.endswith("_J.dat"):
+                        with open(os.path.join(tmp, f), "rb") as src, gzip.GzipFile(os.path.join(HERE, f + ".gz"), "wb", mtime=0) as dst:
+                            dst.write(src.read())
+                    elif f.endswith("_sed.dat"):
+                        shutil.copy(os.path.join(tmp, f), os.path.join(HERE, f))
+                continue
             for f in sorted(os.listdir(tmp)):
                 if f.endswith(".fits") or f.endswith(".dat"):
                     shutil.copy(os.path.join(tmp, f), os.path.join(HERE, f))

@@ -18,6 +18,8 @@ def lib():
         L = C.CDLL(path)
         L.oracle_run_primary.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64,
                                          C.c_void_p, C.c_void_p]
+        L.oracle_run_primary_rf.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_trace_ray.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_void_p]
         _lib = L
@@ -42,6 +44,22 @@ def run_primary(sim, first, count, rng_kind, seed=None, skip_draws=None, frames=
                                   frames.ctypes.data_as(C.c_void_p), C.byref(counters))
     assert rc == 0
     return frames, counters
+
+
+def run_primary_rf(sim, first, count, rng_kind, seed=None, skip_draws=None):
+    """like run_primary for a simulation that stores the radiation field; returns (frames, rf, counters)"""
+    from skirt9_amd.host import CounterValues
+    frames = np.zeros(sim.frame_size, dtype=np.float64)
+    rf = np.zeros(sim.radiation_field_size, dtype=np.float64)
+    if seed is None:
+        seed = sim.seed
+    if skip_draws is None:
+        skip_draws = sim.setup_draws if rng_kind == RNG_MT19937 else 0
+    counters = CounterValues()
+    rc = lib().oracle_run_primary_rf(sim.scene, first, count, rng_kind, seed, skip_draws, frames.ctypes.data_as(C.c_void_p),
+                                     rf.ctypes.data_as(C.c_void_p), C.byref(counters))
+    assert rc == 0
+    return frames, rf, counters
 
 
 def trace_ray(sim, r, k, cap=4096):

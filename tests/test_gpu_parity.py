@@ -121,3 +121,36 @@ def test_fits_output_from_gpu(tmp_path):
     # at 2e4 packets the relative noise R of the total is about 4e-3 -> 5 sigma tolerance
     assert abs(sed[1] - 1.581714115e-06) < 5 * 4e-3 * 1.58e-06
     assert abs(sed[2] - 2.943198361e-06) < 1e-9 * 2.94e-06 + 5 * 4e-3 * 2.94e-06
+
+
+@pytest.mark.parametrize("name,n", [("cfg1rf.ski", 20000), ("cfg3rf.ski", 20000)])
+def test_radiation_field_matches_oracle(name, n):
+    """storeRadiationField on the GPU (walk kernel flavour RF: L * lnmean(e^-tau0, e^-tau1) * ds per path segment, f64
+    atomics into rf[m * nbins + ell]) against the oracle following the same Philox histories: totals to 1e-9, cells
+    with a contribution to 1e-6 relative (summation order and libm last bits); the detector frames must not change"""
+    sim = Simulation(ski(name), num_packets=n).setup()
+    eng = _engine(sim)
+    assert eng.radiation_field_size == sim.radiation_field_size > 0
+    eng.run_primary(0, n, 5)
+    gpu_frames = eng.download()
+    gpu_rf = eng.download_radiation_field()
+    ref_frames, ref_rf, _ = O.run_primary_rf(sim, 0, n, O.RNG_PHILOX, seed=5)
+    assert abs(gpu_rf.sum() - ref_rf.sum()) <= 1e-9 * ref_rf.sum()
+    assert np.array_equal(gpu_rf > 0, ref_rf > 0)
+    bad = np.abs(gpu_rf - ref_rf) > 1e-6 * np.abs(ref_rf) + 1e-13 * ref_rf.max()
+    assert bad.sum() == 0, int(bad.sum())
+    assert abs(gpu_frames.sum() - ref_frames.sum()) <= 1e-9 * np.abs(ref_frames).sum()
+    # accumulation over segments and reset
+    eng.run_primary(n, n, 5)
+    twice = eng.download_radiation_field()
+    assert twice.sum() > 1.9 * gpu_rf.sum()
+    eng.clear_radiation_field()
+    assert eng.download_radiation_field().sum() == 0.
+
+
+def test_radiation_field_absent_unless_requested():
+    sim = Simulation(ski("cfg1.ski"), num_packets=1000).setup()
+    eng = _engine(sim)
+    assert eng.radiation_field_size == 0 and eng.radiation_field_device_ptr == 0
+    with pytest.raises(RuntimeError, match="does not store"):
+        eng.download_radiation_field()

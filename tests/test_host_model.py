@@ -39,7 +39,7 @@ def scene_head(sim):
 def test_cell_densities_bit_exact(name, cells, nodes):
     sim = Simulation(ski(name + ".ski")).setup()
     head = scene_head(sim)
-    assert head.abi_version == 2
+    assert head.abi_version == 3
     assert head.grid.num_cells == cells
     if nodes:
         assert head.grid.kind == 2 and head.grid.num_nodes == nodes

@@ -102,3 +102,23 @@ def test_philox_agrees_with_reference_stream_statistically():
     # the transparent component depends only on the source sampling: relative noise ~ 0 (every packet contributes
     # the same weight), so it must agree to rounding
     assert abs(a[lay.sed_offset] - b[lay.sed_offset]) <= 1e-9 * a[lay.sed_offset]
+
+
+@pytest.mark.parametrize("name", ["cfg1rf", "cfg3rf"])
+def test_radiation_field_probe_byte_identical(name, tmp_path):
+    """storeRadiationField (MonteCarloSimulation.cpp:638-662): with the reference's random stream the oracle's radiation
+    field table, written by the host layer as the RadiationFieldProbe / PerCellForm file, equals the reference's file
+    byte for byte (cfg1rf: oligochromatic, Cartesian grid; cfg3rf: panchromatic, octree, a 6-bin radiation field grid
+    narrower than the source range so that some packets fall outside it); the SED files are unchanged by the option"""
+    import gzip
+    sim = Simulation(ski(name + ".ski")).setup()
+    assert sim.radiation_field_size > 0
+    frames, rf, counters = O.run_primary_rf(sim, 0, sim.num_packets, O.RNG_MT19937)
+    assert counters.histories == sim.num_packets and rf.min() >= 0 and rf.max() > 0
+    sim.write(frames, str(tmp_path))
+    sim.write_radiation_field(rf, str(tmp_path))
+    produced = open(tmp_path / f"{name}_rf_J.dat", "rb").read()
+    assert produced == gzip.open(golden(f"{name}_rf_J.dat.gz"), "rb").read()
+    for f in os.listdir(golden("")):
+        if f.startswith(name + "_i") and f.endswith("_sed.dat"):
+            assert _same_file(golden(f), str(tmp_path / f)), f
