@@ -252,6 +252,8 @@ int64_t pmc_frames_size(pmc_ctx* ctx);
    pointer, copy to the host, reset to zero.  Like the frames it is ACCUMULATED into by every pmc_run_primary. */
 int64_t pmc_radiation_field_size(pmc_ctx* ctx);
 double* pmc_radiation_field_device(pmc_ctx* ctx);
+/* caller-owned DEVICE memory for the table (num_doubles f64, zero-initialised by the caller), e.g. a torch tensor */
+int pmc_bind_radiation_field(pmc_ctx* ctx, double* device_ptr, int64_t num_doubles);
 int pmc_download_radiation_field(pmc_ctx* ctx, double* host_rf, int64_t num_doubles);
 int pmc_clear_radiation_field(pmc_ctx* ctx);
 /* milliseconds spent in the walk kernel (the dominant kernel) during the most recent pmc_run_primary, summed over

@@ -38,6 +38,11 @@ int64_t  skh_frame_size(const skh_simulation* sim);
 int skh_frame_layout(const skh_simulation* sim, int32_t instrument, pmc_frame_layout* out);
 /* calibrates `frames` in place and writes <prefix>_<instrument>_*.fits / _sed.dat / _sedstats.dat into outdir */
 int skh_write(const skh_simulation* sim, double* frames, const char* outdir);
+/* radiation field (RadiationFieldOptions::storeRadiationField): doubles of the table rf[m * nbins + ell] that
+   pmc_download_radiation_field fills (0: not stored), and the RadiationFieldProbe / PerCellForm files
+   <prefix>_<probe>_J.dat written from it (RadiationFieldProbe.cpp:27-78, PerCellForm.cpp:14-32) */
+int64_t  skh_radiation_field_size(const skh_simulation* sim);
+int skh_write_radiation_field(const skh_simulation* sim, const double* rf, const char* outdir);
 int skh_summary(const skh_simulation* sim, char* buffer, int32_t capacity);
 
 #ifdef __cplusplus

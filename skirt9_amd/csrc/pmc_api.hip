@@ -835,6 +835,16 @@ double* pmc_radiation_field_device(pmc_ctx* ctx)
     return ctx ? ctx->dev.rf : nullptr;
 }
 
+int pmc_bind_radiation_field(pmc_ctx* ctx, double* device_ptr, int64_t num_doubles)
+{
+    if (!ctx || !device_ptr) return fail(PMC_ERR_INVALID, "null argument");
+    if (!ctx->rfSize) return fail(PMC_ERR_INVALID, "the scene does not store the radiation field");
+    if (num_doubles != ctx->rfSize) return fail(PMC_ERR_INVALID, "radiation field size mismatch");
+    ctx->dev.rf = device_ptr;
+    ctx->sceneDirty = true;
+    return PMC_OK;
+}
+
 int pmc_download_radiation_field(pmc_ctx* ctx, double* host_rf, int64_t num_doubles)
 {
     if (!ctx || !host_rf) return fail(PMC_ERR_INVALID, "null argument");

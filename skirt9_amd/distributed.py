@@ -24,3 +24,14 @@ def reduce_frames(frames, dst=0):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(frames, dst=dst, op=dist.ReduceOp.SUM)
     return frames
+
+
+def allreduce_radiation_field(rf):
+    """sum the radiation field table of every rank onto ALL ranks (in place): the counterpart of
+    MediumSystem::communicateRadiationField (MediumSystem.cpp:1304-1313, ProcessManager::sumToAll) -- every process
+    needs the whole field for what follows the primary segment (dust emission).  `rf` is a float64 tensor that aliases
+    pmc_radiation_field_device() (or a gloo tensor in the CPU tests); no-op for a single process"""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(rf, op=dist.ReduceOp.SUM)
+    return rf

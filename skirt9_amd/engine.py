@@ -19,7 +19,7 @@ SYMBOLS = ["pmc_abi_version", "pmc_last_error", "pmc_frame_layout_of", "pmc_crea
            "pmc_clear_frames", "pmc_run_primary", "pmc_sync", "pmc_download", "pmc_frames_device", "pmc_frames_size",
            "pmc_last_kernel_ms", "pmc_counters", "pmc_reset_counters", "pmc_trace_ray", "pmc_set_launch",
            "pmc_set_num_slots", "pmc_last_timing", "pmc_radiation_field_size", "pmc_radiation_field_device",
-           "pmc_download_radiation_field", "pmc_clear_radiation_field"]
+           "pmc_download_radiation_field", "pmc_clear_radiation_field", "pmc_bind_radiation_field"]
 
 _lib = None
 
@@ -61,6 +61,7 @@ def lib():
         L.pmc_radiation_field_device.argtypes = [C.c_void_p]
         L.pmc_download_radiation_field.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.pmc_clear_radiation_field.argtypes = [C.c_void_p]
+        L.pmc_bind_radiation_field.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         _lib = L
     return _lib
 
@@ -143,6 +144,11 @@ class Engine:
     def radiation_field_device_ptr(self):
         """device address of the radiation field table (for an RCCL all-reduce across ranks)"""
         return int(lib().pmc_radiation_field_device(self._h) or 0)
+
+    def bind_radiation_field(self, device_ptr, num_doubles):
+        """accumulate the radiation field into caller-owned device memory (a zeroed float64 torch tensor), so that
+        torch.distributed can all-reduce it over RCCL (skirt9_amd.distributed.allreduce_radiation_field)"""
+        _check(lib().pmc_bind_radiation_field(self._h, C.c_void_p(device_ptr), num_doubles))
 
     def download_radiation_field(self):
         """rf[m * nbins + ell] accumulated by the segments run so far (MediumSystem::_rf1)"""

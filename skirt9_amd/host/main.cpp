@@ -83,6 +83,22 @@ int main(int argc, char** argv)
         fprintf(stderr, "Fatal error: %s\n", skh_last_error());
         return 1;
     }
+    // the radiation field, if the ski file stores it: downloaded after the segment and written by the configured
+    // RadiationFieldProbe (the reference sums it over processes first, MediumSystem.cpp:1304-1313; one GPU here)
+    if (const int64_t rfSize = skh_radiation_field_size(sim))
+    {
+        std::vector<double> rf(rfSize);
+        if (pmc_download_radiation_field(ctx, rf.data(), rfSize) != PMC_OK)
+        {
+            fprintf(stderr, "Fatal error: %s\n", pmc_last_error());
+            return 1;
+        }
+        if (skh_write_radiation_field(sim, rf.data(), outdir.c_str()) != 0)
+        {
+            fprintf(stderr, "Fatal error: %s\n", skh_last_error());
+            return 1;
+        }
+    }
     printf("Finished final output in %.1f s.\n", seconds(t3, clock::now()));
     pmc_destroy(ctx);
     skh_free(sim);

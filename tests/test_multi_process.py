@@ -57,3 +57,37 @@ def test_two_ranks_equal_one(tmp_path):
     lay = sim.layout(0)
     assert both[lay.wsed_offset] == n  # every history counted once
     assert np.allclose(both, single, rtol=1e-12, atol=0)
+
+
+def _rf_worker(rank, world, port, n, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from skirt9_amd.distributed import allreduce_radiation_field, history_range
+    from skirt9_amd.host import Simulation
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sim = Simulation(ski("cfg3rf.ski"), num_packets=n).setup()
+    first, count = history_range(n, rank, world)
+    _, rf, _ = O.run_primary_rf(sim, first, count, O.RNG_PHILOX, seed=3)
+    t = torch.from_numpy(rf)
+    allreduce_radiation_field(t)
+    np.save(os.path.join(outdir, f"rf{rank}.npy"), t.numpy())  # every rank must hold the whole field (sumToAll)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_radiation_field_allreduce_two_ranks(tmp_path):
+    """MediumSystem::communicateRadiationField (MediumSystem.cpp:1304-1313): the per-rank tables add up, on EVERY rank,
+    to the table of the undivided segment"""
+    import oracle_lib as O
+    from skirt9_amd.host import Simulation
+    n = 3001
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_rf_worker, args=(2, port, n, str(tmp_path)), nprocs=2, join=True)
+    sim = Simulation(ski("cfg3rf.ski"), num_packets=n).setup()
+    _, single, _ = O.run_primary_rf(sim, 0, n, O.RNG_PHILOX, seed=3)
+    for rank in (0, 1):
+        both = np.load(tmp_path / f"rf{rank}.npy")
+        assert np.allclose(both, single, rtol=1e-12, atol=0) and both.sum() > 0
