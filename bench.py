@@ -105,6 +105,9 @@ def main():
                          "panchromatic with a 50-bin wavelength grid (tests/ski/cfg3.ski); 4: BASELINE configs[3], the same "
                          "Sersic source in dust imported from 10^6 smoothed particles (tests/ski/cfg4.ski; the particle file "
                          "is regenerated by tools/make_sph.py)")
+    ap.add_argument("--store-radiation-field", action="store_true",
+                    help="run the same workload with RadiationFieldOptions storeRadiationField=true (the RF flavour of the "
+                         "walk kernel: one exp, one lnmean and one f64 atomic more per path segment); not the headline number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -154,6 +157,13 @@ def main():
             raise SystemExit("--source uniform: no SersicGeometry source in the ski file")
         ski_path = os.path.join(tempfile.mkdtemp(prefix=f"bench_r{rank}_"), "cfg2u.ski")
         open(ski_path, "w").write(text)
+    if args.store_radiation_field:
+        text = open(ski_path).read()
+        if 'storeRadiationField="false"' not in text:
+            raise SystemExit("--store-radiation-field: the ski file has no storeRadiationField=\"false\" to switch")
+        rf_ski = os.path.join(tempfile.mkdtemp(prefix=f"bench_rf_r{rank}_"), os.path.basename(ski_path))
+        open(rf_ski, "w").write(text.replace('storeRadiationField="false"', 'storeRadiationField="true"'))
+        ski_path = rf_ski
     sim = Simulation(ski_path, num_packets=total_per_step).setup()
     eng = Engine(sim.scene, local_rank)
     frames = torch.zeros(sim.frame_size, dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -226,6 +236,7 @@ def main():
                                    "FullInstrument 512^2 (components + statistics), " + os.path.relpath(args.ski, ROOT),
                        "packets_per_step_per_gpu": P,
                        "cells": 953688 if (args.ski == SKI or args.config == 3) else 985979 if args.config == 4 else None,
+                       "store_radiation_field": bool(args.store_radiation_field),
                        "parallelism": f"history-range x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(P) if (args.ski == SKI and args.source == "sersic") else None,
