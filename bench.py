@@ -124,10 +124,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    # testing aid for a 1-GPU box: BENCH_SHARE_DEVICE=1 runs all ranks on device 0 and exchanges over gloo (RCCL refuses
+    # two ranks on one device); the history split, the per-step reduce and the timing protocol are the same
+    share = world > 1 and os.environ.get("BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     P = int(args.packets)
     total_per_step = P * world
@@ -176,7 +184,12 @@ def main():
         eng.run_primary(first, P, seed)
         eng.sync()
         if world > 1:
-            dist.reduce(frames, dst=0, op=dist.ReduceOp.SUM)
+            if share:
+                dist.all_reduce(frames, op=dist.ReduceOp.SUM)  # (gloo has no GPU reduce)
+            else:
+                dist.reduce(frames, dst=0, op=dist.ReduceOp.SUM)
+            if rank != 0:
+                frames.zero_()  # rank 0 holds the sum so far; the others start the next segment from zero
 
     def fence():
         if world > 1:
