@@ -46,7 +46,7 @@ enum { PMC_OK = 0, PMC_ERR_INVALID = -1, PMC_ERR_UNSUPPORTED = -2, PMC_ERR_DEVIC
 
 /* ---------------------------------------------------------------- spatial grid ---- */
 
-enum { PMC_GRID_CARTESIAN = 1, PMC_GRID_OCTREE = 2 };
+enum { PMC_GRID_CARTESIAN = 1, PMC_GRID_OCTREE = 2, PMC_GRID_VORONOI = 3 };
 
 /* walls in the reference's order (SKIRT/core/TreeNode.hpp enum Wall): BACK=-x, FRONT=+x, LEFT=-y, RIGHT=+y,
    BOTTOM=-z, TOP=+z */
@@ -79,6 +79,20 @@ typedef struct pmc_grid
     const int32_t* node_cell;
     const int32_t* nbr_start;     /* 6*num_nodes + 1 */
     const int32_t* nbr_list;
+
+    /* --- Voronoi (VoronoiMeshSnapshot.cpp:1058-1188): cell m = Voronoi cell of site m inside the domain box.
+       site[3*m + {0,1,2}] = site position (the reference's order: sorted by x, :509);
+       neighbours of cell m: vnbr_list[ vnbr_start[m] .. vnbr_start[m+1] ) = site indices, or -1..-6 for the domain walls
+       xmin, xmax, ymin, ymax, zmin, zmax (the Voro++ convention, :1137-1147);
+       nearest-site search (VoronoiMeshSnapshot::cellIndex, :1006-1040): a grid of vblock_n^3 blocks over the domain
+       (Box::cellIndices), block b = (i*n + j)*n + k lists the cells whose bounding box overlaps it in
+       vblock_list[ vblock_start[b] .. vblock_start[b+1] ). */
+    const double*  site;
+    const int32_t* vnbr_start;    /* num_cells + 1 */
+    const int32_t* vnbr_list;
+    int32_t        vblock_n;
+    const int32_t* vblock_start;  /* vblock_n^3 + 1 */
+    const int32_t* vblock_list;
 } pmc_grid;
 
 /* ---------------------------------------------------------------- medium ---- */

@@ -352,6 +352,117 @@ namespace
         }
     };
 
+    // VoronoiMeshSnapshot::MySegmentGenerator (VoronoiMeshSnapshot.cpp:1058-1188) with VoronoiMeshSnapshot::cellIndex
+    // (:1006-1040: nearest site among the cells listed for the block of the position)
+    struct VoronoiGenerator : Generator
+    {
+        int mr{-1};
+        using Generator::Generator;
+        int cellIndex(double x, double y, double z) const
+        {
+            if (!extent().contains(x, y, z)) return -1;
+            const int nb = g.vblock_n;
+            int i = std::max(0, std::min(nb - 1, static_cast<int>(nb * (x - g.xmin) / (g.xmax - g.xmin))));
+            int j = std::max(0, std::min(nb - 1, static_cast<int>(nb * (y - g.ymin) / (g.ymax - g.ymin))));
+            int k = std::max(0, std::min(nb - 1, static_cast<int>(nb * (z - g.zmin) / (g.zmax - g.zmin))));
+            const size_t b = (static_cast<size_t>(i) * nb + j) * nb + k;
+            int best = -1;
+            double mdist = DBL_MAX;
+            for (int q = g.vblock_start[b]; q != g.vblock_start[b + 1]; ++q)
+            {
+                const int id = g.vblock_list[q];
+                double dx = x - g.site[3 * id], dy = y - g.site[3 * id + 1], dz = z - g.site[3 * id + 2];
+                double idist = dx * dx + dy * dy + dz * dz;
+                if (idist < mdist)
+                {
+                    best = id;
+                    mdist = idist;
+                }
+            }
+            return best;
+        }
+        bool next() override
+        {
+            switch (state)
+            {
+                case State::Unknown:
+                {
+                    if (!moveInside(extent(), g.eps)) return false;
+                    mr = cellIndex(rx, ry, rz);
+                    if (ds > 0.) return true;
+                }
+                // intentionally falls through
+                case State::Inside:
+                {
+                    while (true)
+                    {
+                        const double prx = g.site[3 * mr], pry = g.site[3 * mr + 1], prz = g.site[3 * mr + 2];
+                        double sq = DBL_MAX;
+                        const int NO_INDEX = -99;
+                        int mq = NO_INDEX;
+                        for (int q = g.vnbr_start[mr]; q != g.vnbr_start[mr + 1]; ++q)
+                        {
+                            int mi = g.vnbr_list[q];
+                            double si = 0;
+                            if (mi >= 0)
+                            {
+                                const double pix = g.site[3 * mi], piy = g.site[3 * mi + 1], piz = g.site[3 * mi + 2];
+                                const double nx = pix - prx, ny = piy - pry, nz = piz - prz;
+                                double ndotk = nx * kx + ny * ky + nz * kz;
+                                if (ndotk > 0)
+                                {
+                                    const double px = 0.5 * (pix + prx), py = 0.5 * (piy + pry), pz = 0.5 * (piz + prz);
+                                    si = (nx * (px - rx) + ny * (py - ry) + nz * (pz - rz)) / ndotk;
+                                }
+                            }
+                            else
+                            {
+                                switch (mi)
+                                {
+                                    case -1: si = (g.xmin - rx) / kx; break;
+                                    case -2: si = (g.xmax - rx) / kx; break;
+                                    case -3: si = (g.ymin - ry) / ky; break;
+                                    case -4: si = (g.ymax - ry) / ky; break;
+                                    case -5: si = (g.zmin - rz) / kz; break;
+                                    case -6: si = (g.zmax - rz) / kz; break;
+                                    default: break;
+                                }
+                            }
+                            if (si > 0 && si < sq)
+                            {
+                                sq = si;
+                                mq = mi;
+                            }
+                        }
+                        if (mq == NO_INDEX)
+                        {
+                            propagater(g.eps);
+                            mr = cellIndex(rx, ry, rz);
+                            if (mr < 0)
+                            {
+                                state = State::Outside;
+                                return false;
+                            }
+                        }
+                        else
+                        {
+                            propagater(sq + g.eps);
+                            m = mr;
+                            ds = sq;
+                            mr = mq;
+                            if (mr < 0) state = State::Outside;
+                            return true;
+                        }
+                    }
+                }
+                case State::Outside:
+                {
+                }
+            }
+            return false;
+        }
+    };
+
     // TreeSpatialGrid::MySegmentGenerator (TreeSpatialGrid.cpp:132-217) over the flattened node list
     struct TreeGenerator : Generator
     {
@@ -496,6 +607,8 @@ namespace
         {
             if (sc.grid.kind == PMC_GRID_CARTESIAN)
                 generator.reset(new CartesianGenerator(sc.grid));
+            else if (sc.grid.kind == PMC_GRID_VORONOI)
+                generator.reset(new VoronoiGenerator(sc.grid));
             else
                 generator.reset(new TreeGenerator(sc.grid));
             layouts.resize(sc.num_instruments);
@@ -1145,6 +1258,8 @@ int oracle_trace_ray(const pmc_scene* scene, const double r[3], const double k[3
     std::unique_ptr<Generator> gen;
     if (scene->grid.kind == PMC_GRID_CARTESIAN)
         gen.reset(new CartesianGenerator(scene->grid));
+    else if (scene->grid.kind == PMC_GRID_VORONOI)
+        gen.reset(new VoronoiGenerator(scene->grid));
     else
         gen.reset(new TreeGenerator(scene->grid));
     gen->start(V3{r[0], r[1], r[2]}, V3{k[0], k[1], k[2]});

@@ -379,7 +379,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     if (scene->abi_version != PMC_ABI_VERSION) return fail(PMC_ERR_INVALID, "pmc_scene ABI version mismatch");
     if (scene->num_instruments < 1 || scene->num_instruments > PMC_MAX_INSTRUMENTS)
         return fail(PMC_ERR_UNSUPPORTED, "between 1 and " + std::to_string(PMC_MAX_INSTRUMENTS) + " instruments are supported");
-    if (scene->grid.kind != PMC_GRID_CARTESIAN && scene->grid.kind != PMC_GRID_OCTREE)
+    if (scene->grid.kind != PMC_GRID_CARTESIAN && scene->grid.kind != PMC_GRID_OCTREE && scene->grid.kind != PMC_GRID_VORONOI)
         return fail(PMC_ERR_UNSUPPORTED, "unsupported grid kind");
     if (scene->instruments[0].same_observer_as_preceding) return fail(PMC_ERR_INVALID, "first instrument cannot share an observer");
 
@@ -439,6 +439,30 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         D.lmax = 0;
         if (g.nx > 1024 || g.ny > 1024 || g.nz > 1024)
             return bail(fail(PMC_ERR_UNSUPPORTED, "Cartesian grids with more than 1024 cells per axis are not supported"));
+    }
+    else if (g.kind == PMC_GRID_VORONOI)
+    {
+        if (g.num_cells < 1 || !g.site || !g.vnbr_start || !g.vnbr_list || g.vblock_n < 1 || !g.vblock_start || !g.vblock_list)
+            return bail(fail(PMC_ERR_INVALID, "Voronoi grid tables are missing"));
+        std::vector<double> rec(4 * size_t(g.num_cells));
+        for (int m = 0; m < g.num_cells; ++m)
+        {
+            rec[4 * size_t(m)] = g.site[3 * size_t(m)], rec[4 * size_t(m) + 1] = g.site[3 * size_t(m) + 1];
+            rec[4 * size_t(m) + 2] = g.site[3 * size_t(m) + 2], rec[4 * size_t(m) + 3] = scene->medium.number_density[m];
+        }
+        const size_t nb3 = size_t(g.vblock_n) * g.vblock_n * g.vblock_n;
+        for (int m = 0; m < g.num_cells; ++m)
+            for (int q = g.vnbr_start[m]; q < g.vnbr_start[m + 1]; ++q)
+                if (g.vnbr_list[q] < -6 || g.vnbr_list[q] >= g.num_cells)
+                    return bail(fail(PMC_ERR_INVALID, "Voronoi neighbour list holds an invalid index"));
+        if ((rc = ctx->upload(rec.data(), rec.size(), &D.vsite))) return bail(rc);
+        if ((rc = ctx->upload(g.vnbr_start, size_t(g.num_cells) + 1, &D.vnbr_start))) return bail(rc);
+        if ((rc = ctx->upload(g.vnbr_list, size_t(g.vnbr_start[g.num_cells]), &D.vnbr_list))) return bail(rc);
+        D.vblock_n = g.vblock_n;
+        if ((rc = ctx->upload(g.vblock_start, nb3 + 1, &D.vblock_start))) return bail(rc);
+        if ((rc = ctx->upload(g.vblock_list, size_t(g.vblock_start[nb3]), &D.vblock_list))) return bail(rc);
+        D.lds_grid_len = 0;
+        D.lmax = 0;
     }
     else
     {

@@ -146,6 +146,14 @@ struct DevScene
     const int32_t* nbr_start;    // [6*num_cells + 1]
     const int32_t* nbr_list;     // leaf cell indices
     int32_t num_cells;
+    // Voronoi (pmc_grid::site ...): site positions as double4-aligned records {x, y, z, number density}, so that one
+    // 32-byte gather brings everything the traversal needs of a neighbour or of the cell itself
+    const double* vsite;          // [num_cells][4]
+    const int32_t* vnbr_start;    // [num_cells + 1]
+    const int32_t* vnbr_list;
+    int32_t vblock_n;
+    const int32_t* vblock_start;  // [vblock_n^3 + 1]
+    const int32_t* vblock_list;
     // ---- medium
     int32_t num_lambda;
     const double* lambda_border;

@@ -76,7 +76,7 @@ __constant__ DevScene c_scene[PMC_MAX_CONTEXTS];
 namespace
 {
     enum Mode : int { MODE_PASS1 = 0, MODE_PASS2 = 1, MODE_PEEL = 2, MODE_NONE = 3 };
-    enum Grid : int { GRID_CART = PMC_GRID_CARTESIAN, GRID_TREE = PMC_GRID_OCTREE };
+    enum Grid : int { GRID_CART = PMC_GRID_CARTESIAN, GRID_TREE = PMC_GRID_OCTREE, GRID_VORO = PMC_GRID_VORONOI };
     constexpr int MODE_ALIVE = 1 << 5;
 
     // ------------------------------------------------------------------------------------------------
@@ -185,7 +185,12 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
                {reinterpret_cast<const void*>(&transitionKernel<GRID_TREE>), transitionLds},
                {reinterpret_cast<const void*>(&transitionKernel<GRID_CART>), transitionLds},
                {reinterpret_cast<const void*>(&launchKernel<GRID_TREE>), transitionLds},
-               {reinterpret_cast<const void*>(&launchKernel<GRID_CART>), transitionLds}};
+               {reinterpret_cast<const void*>(&launchKernel<GRID_CART>), transitionLds},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false>), walkLds},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, true>), walkLds},
+               {reinterpret_cast<const void*>(&traceRayKernel<GRID_VORO>), walkLds},
+               {reinterpret_cast<const void*>(&transitionKernel<GRID_VORO>), transitionLds},
+               {reinterpret_cast<const void*>(&launchKernel<GRID_VORO>), transitionLds}};
     for (const auto& k : all)
     {
         hipError_t e = hipFuncSetAttribute(k.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds);
@@ -200,6 +205,8 @@ extern "C" int pmcWalkBlocksPerCU(int gridKind, int block, size_t ldsBytes)
     hipError_t e;
     if (gridKind == PMC_GRID_OCTREE)
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_TREE, false>), block, ldsBytes);
+    else if (gridKind == PMC_GRID_VORONOI)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false>), block, ldsBytes);
     else
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_CART, false>), block, ldsBytes);
     return e == hipSuccess ? n : 0;
@@ -211,8 +218,9 @@ extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int tas
                                     uint64_t seed, int grid, int block, size_t ldsBytes, hipStream_t stream)
 {
     // (the radiation-field flavour is a separate instantiation: the plain photon loop pays nothing for it)
-    auto kernel = gridKind == PMC_GRID_OCTREE ? (storeRf ? walkKernel<GRID_TREE, true> : walkKernel<GRID_TREE, false>)
-                                              : (storeRf ? walkKernel<GRID_CART, true> : walkKernel<GRID_CART, false>);
+    auto kernel = gridKind == PMC_GRID_OCTREE    ? (storeRf ? walkKernel<GRID_TREE, true> : walkKernel<GRID_TREE, false>)
+                  : gridKind == PMC_GRID_VORONOI ? (storeRf ? walkKernel<GRID_VORO, true> : walkKernel<GRID_VORO, false>)
+                                                 : (storeRf ? walkKernel<GRID_CART, true> : walkKernel<GRID_CART, false>);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter, seed);
     return hipGetLastError();
 }
@@ -226,6 +234,9 @@ extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, 
     const int grid = std::max(1, std::min((numSlots + block - 1) / block, maxBlocks));
     if (gridKind == PMC_GRID_OCTREE)
         hipLaunchKernelGGL(transitionKernel<GRID_TREE>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group,
+                           listBase, shardCap, seed);
+    else if (gridKind == PMC_GRID_VORONOI)
+        hipLaunchKernelGGL(transitionKernel<GRID_VORO>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group,
                            listBase, shardCap, seed);
     else
         hipLaunchKernelGGL(transitionKernel<GRID_CART>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group,
@@ -242,6 +253,9 @@ extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int 
     if (gridKind == PMC_GRID_OCTREE)
         hipLaunchKernelGGL(launchKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, listBase,
                            shardCap, first, count, seed, initial);
+    else if (gridKind == PMC_GRID_VORONOI)
+        hipLaunchKernelGGL(launchKernel<GRID_VORO>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, listBase,
+                           shardCap, first, count, seed, initial);
     else
         hipLaunchKernelGGL(launchKernel<GRID_CART>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, listBase,
                            shardCap, first, count, seed, initial);
@@ -253,6 +267,9 @@ extern "C" hipError_t pmcLaunchTrace(int slot, int gridKind, const double r[3], 
 {
     if (gridKind == PMC_GRID_OCTREE)
         hipLaunchKernelGGL(traceRayKernel<GRID_TREE>, dim3(1), dim3(64), ldsBytes, stream, slot, r[0], r[1], r[2], k[0], k[1],
+                           k[2], m, ds, cap, n);
+    else if (gridKind == PMC_GRID_VORONOI)
+        hipLaunchKernelGGL(traceRayKernel<GRID_VORO>, dim3(1), dim3(64), ldsBytes, stream, slot, r[0], r[1], r[2], k[0], k[1],
                            k[2], m, ds, cap, n);
     else
         hipLaunchKernelGGL(traceRayKernel<GRID_CART>, dim3(1), dim3(64), ldsBytes, stream, slot, r[0], r[1], r[2], k[0], k[1],

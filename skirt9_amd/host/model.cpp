@@ -491,6 +491,54 @@ namespace skh
         finish();
     }
 
+    // ================================================================ VoronoiSpatialGrid
+
+    void VoronoiSpatialGrid::setup(Random& random)
+    {
+        std::vector<Vec3> sites;
+        if (policy == "Uniform")
+        {
+            // VoronoiMeshSpatialGrid.cpp:49-55: numSites positions from the simulation's random stream
+            sites.resize(numSites);
+            for (int m = 0; m != numSites; ++m) sites[m] = random.position(extent);
+        }
+        else
+        {
+            // VoronoiMeshSnapshot.cpp:408-417
+            auto rows = readColumnFile(sitesPath, {{"position x", "length", "pc"}, {"position y", "length", "pc"}, {"position z", "length", "pc"}},
+                                       "Voronoi sites");
+            for (const Array& row : rows) sites.push_back(Vec3{row[0], row[1], row[2]});
+        }
+        mesh.build(extent, std::move(sites));
+    }
+
+    Vec3 VoronoiSpatialGrid::randomPositionInCell(int m, Random& random) const
+    {
+        const Box& box = mesh.cellBox(m);
+        for (int i = 0; i < 10000; i++)
+        {
+            Vec3 r = random.position(box);
+            if (mesh.isPointClosestTo(r, m)) return r;
+        }
+        throw std::runtime_error("Can't find random position in cell");
+    }
+
+    void VoronoiSpatialGrid::fill(pmc_grid& g) const
+    {
+        g = pmc_grid{};
+        g.kind = PMC_GRID_VORONOI;
+        g.xmin = extent.xmin, g.ymin = extent.ymin, g.zmin = extent.zmin;
+        g.xmax = extent.xmax, g.ymax = extent.ymax, g.zmax = extent.zmax;
+        g.eps = mesh.eps();
+        g.num_cells = mesh.numCells();
+        g.site = mesh.flatSites().data();
+        g.vnbr_start = mesh.nbrStart().data();
+        g.vnbr_list = mesh.nbrList().data();
+        g.vblock_n = mesh.numBlocks();
+        g.vblock_start = mesh.blockStart().data();
+        g.vblock_list = mesh.blockList().data();
+    }
+
     void OctreeSpatialGrid::setupFromTopology(const std::vector<char>& topology)
     {
         // first pass: depth-first reconstruction of parent/child relations on temporary ids

@@ -9,6 +9,7 @@
 #include "../../include/pmc.h"
 #include "mathutil.hpp"
 #include "particles.hpp"
+#include "voronoi.hpp"
 #include "xml.hpp"
 #include <memory>
 #include <string>
@@ -241,8 +242,12 @@ namespace skh
         virtual ~SpatialGrid() {}
         Box extent;
         virtual int numCells() const = 0;
-        virtual Box cellBox(int m) const = 0;
+        virtual Box cellBox(int m) const = 0;  // box cells: the cell; Voronoi: the bounding box of the cell
         virtual void fill(pmc_grid& g) const = 0;
+        // SpatialGrid::volume / centralPositionInCell / randomPositionInCell
+        virtual double volume(int m) const { return cellBox(m).volume(); }
+        virtual Vec3 centralPositionInCell(int m) const { return cellBox(m).center(); }
+        virtual Vec3 randomPositionInCell(int m, Random& random) const { return random.position(cellBox(m)); }
     };
 
     // CartesianSpatialGrid with LinMesh axes (CartesianSpatialGrid.cpp:14-28, LinMesh.cpp:11-16)
@@ -293,6 +298,26 @@ namespace skh
     private:
         void subdivide(int id);
         void finish();
+    };
+
+    // VoronoiMeshSpatialGrid (VoronoiMeshSpatialGrid.cpp:42-121) with the policies Uniform (random sites) and File
+    // (sites from a column text file); the tessellation itself is voronoi.hpp
+    class VoronoiSpatialGrid : public SpatialGrid
+    {
+    public:
+        std::string policy{"Uniform"};
+        int numSites{500};
+        std::string sitesPath;  // resolved file path (policy File)
+        VoronoiMesh mesh;
+
+        void setup(Random& random);
+        int numCells() const override { return mesh.numCells(); }
+        Box cellBox(int m) const override { return mesh.cellBox(m); }
+        void fill(pmc_grid& g) const override;
+        double volume(int m) const override { return mesh.volume(m); }
+        Vec3 centralPositionInCell(int m) const override { return mesh.site(m); }
+        // VoronoiMeshSnapshot::generatePosition(m) (:976-989): rejection sampling in the bounding box
+        Vec3 randomPositionInCell(int m, Random& random) const override;
     };
 
     // ---------------------------------------------------------------- source

@@ -287,7 +287,7 @@ namespace skh
             for (int m = 0; m != numCells; ++m)
             {
                 // MediumSystem::meanIntensity
-                double factor = 1. / (4. * M_PI * _grid->cellBox(m).volume());
+                double factor = 1. / (4. * M_PI * _grid->volume(m));
                 std::string line = std::to_string(m);
                 for (int i = 0; i != nbins; ++i)
                 {

@@ -395,6 +395,23 @@ namespace skh
             }
             _grid = std::move(grid);
         }
+        else if (ge->name == "VoronoiMeshSpatialGrid")
+        {
+            // VoronoiMeshSpatialGrid.hpp: policies Uniform (random sites) and File (sites from a column text file)
+            auto grid = std::make_unique<VoronoiSpatialGrid>();
+            grid->extent = extent;
+            grid->policy = ge->attr("policy", "DustDensity");
+            if (grid->policy != "Uniform" && grid->policy != "File") unsupported("Voronoi site policy " + grid->policy);
+            grid->numSites = rd.integer(*ge, "numSites", 500);
+            if (grid->policy == "File")
+            {
+                std::string filename = ge->attr("filename", "");
+                if (filename.empty()) throw std::runtime_error("ski: VoronoiMeshSpatialGrid lacks a filename");
+                grid->sitesPath = (filename[0] == '/') ? filename : _inputPath + "/" + filename;
+            }
+            if (rd.boolean(*ge, "relaxSites", false)) unsupported("relaxSites");
+            _grid = std::move(grid);
+        }
         else
             unsupported("spatial grid " + ge->name);
 
@@ -526,13 +543,15 @@ namespace skh
             else
                 tree->setup(*_medium, _numDensitySamples, _random);
         }
+        else if (auto voro = dynamic_cast<VoronoiSpatialGrid*>(_grid.get()))
+            voro->setup(_random);
 
         // MediumSystem::setupSelfAfter density sampling (MediumSystem.cpp:80-106,308-321)
         int numCells = _grid->numCells();
         _density.assign(numCells, 0.);
         if (_numDensitySamples == 1)
         {
-            for (int m = 0; m != numCells; ++m) _density[m] = _medium->numberDensity(_grid->cellBox(m).center());
+            for (int m = 0; m != numCells; ++m) _density[m] = _medium->numberDensity(_grid->centralPositionInCell(m));
         }
         else
         {
@@ -546,8 +565,7 @@ namespace skh
                 pos.clear();
                 for (int m = m0; m != m1; ++m)
                 {
-                    Box box = _grid->cellBox(m);
-                    for (int n = 0; n != _numDensitySamples; ++n) pos.push_back(_random.position(box));
+                    for (int n = 0; n != _numDensitySamples; ++n) pos.push_back(_grid->randomPositionInCell(m, _random));
                 }
                 samples.resize(pos.size());
                 parallelFor(pos.size(), [&](size_t b, size_t e) {
@@ -775,7 +793,7 @@ namespace skh
         std::ostringstream s;
         s << "simulation " << _prefix << ": " << (_oligo ? "oligochromatic" : "panchromatic") << ", " << _numPackets
           << " packets, seed " << _seed << "\n";
-        s << "  grid: " << (_scene.grid.kind == PMC_GRID_CARTESIAN ? "Cartesian" : "octree") << " with " << _scene.grid.num_cells
+        s << "  grid: " << (_scene.grid.kind == PMC_GRID_CARTESIAN ? "Cartesian" : _scene.grid.kind == PMC_GRID_VORONOI ? "Voronoi" : "octree") << " with " << _scene.grid.num_cells
           << " cells";
         if (_scene.grid.kind == PMC_GRID_OCTREE) s << " (" << _scene.grid.num_nodes << " nodes)";
         s << "\n  dust table: " << _scene.medium.num_lambda << " wavelengths; setup draws: " << _random.draws() << "\n";

@@ -13,6 +13,9 @@ Fixtures:
   cfg1file_*   config 1 with MeanFileDustMix (tests/ski/cfg1file.ski + cfg1file_dust.txt): 10^5 packets -> files
   cfg1rf_*, cfg3rf_*   config 1 and reduced config 3 with storeRadiationField and a RadiationFieldProbe (PerCellForm):
                the probe file <name>_rf_J.dat (gzip) and the SED files
+  cfg5small_*  reduced config 5 (tests/ski/cfg5small.ski): Voronoi grid with 1500 random sites, panchromatic, four
+               instruments -> files, rays, cells (the host layer's tessellation is its own: the traversal is compared bit
+               for bit, cell volumes to rounding, sampled densities and output files statistically)
   cfg4small_*  reduced config 4 (tests/ski/cfg4small.ski): dust imported from 3000 smoothed particles
                (tests/ski/cfg4small_sph.txt, made by tools/make_sph.py), 2x10^4 packets -> files, rays, cells
   *_rays.txt / *_rays_ref.txt   fixed rays and the reference's (m, ds) sequences (C99 hex floats)
@@ -52,7 +55,8 @@ def main():
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
     for name, scale in (("cfg1", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg3small", None), ("cfg1nf", None),
-                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1rf", "rf"), ("cfg3rf", "rf")):
+                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1rf", "rf"), ("cfg3rf", "rf"),
+                        ("cfg5small", 4000 * 3.08567758e16)):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         ski = os.path.join(ROOT, "tests", "ski", name + ".ski")

@@ -17,7 +17,9 @@ class Grid(C.Structure):
                 ("xv", C.POINTER(C.c_double)), ("yv", C.POINTER(C.c_double)), ("zv", C.POINTER(C.c_double)),
                 ("num_nodes", C.c_int32), ("node_box", C.POINTER(C.c_double)), ("node_level", C.POINTER(C.c_int32)),
                 ("node_first_child", C.POINTER(C.c_int32)), ("node_cell", C.POINTER(C.c_int32)),
-                ("nbr_start", C.POINTER(C.c_int32)), ("nbr_list", C.POINTER(C.c_int32))]
+                ("nbr_start", C.POINTER(C.c_int32)), ("nbr_list", C.POINTER(C.c_int32)),
+                ("site", C.POINTER(C.c_double)), ("vnbr_start", C.POINTER(C.c_int32)), ("vnbr_list", C.POINTER(C.c_int32)),
+                ("vblock_n", C.c_int32), ("vblock_start", C.POINTER(C.c_int32)), ("vblock_list", C.POINTER(C.c_int32))]
 
 
 class Medium(C.Structure):
