@@ -100,11 +100,12 @@ def main():
     ap.add_argument("--source", choices=["sersic", "uniform"], default="sersic",
                     help="sersic: cfg2.ski as is (the headline workload); uniform: the same scene with the Sersic source "
                          "replaced by a UniformBoxGeometry source of +-10 x +-10 x +-1 kpc (north_star's second source)")
-    ap.add_argument("--config", type=int, choices=[2, 3, 4], default=2,
+    ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=2,
                     help="2: BASELINE configs[1] (the headline workload, tests/ski/cfg2.ski); 3: BASELINE configs[2], the same scene "
                          "panchromatic with a 50-bin wavelength grid (tests/ski/cfg3.ski); 4: BASELINE configs[3], the same "
                          "Sersic source in dust imported from 10^6 smoothed particles (tests/ski/cfg4.ski; the particle file "
-                         "is regenerated by tools/make_sph.py)")
+                         "is regenerated by tools/make_sph.py); 5: BASELINE configs[4], the config-3 scene on a Voronoi grid of 10^5 sites "
+                         "(tests/ski/cfg5.ski; sites regenerated by tools/make_sites.py), three instruments")
     ap.add_argument("--store-radiation-field", action="store_true",
                     help="run the same workload with RadiationFieldOptions storeRadiationField=true (the RF flavour of the "
                          "walk kernel: one exp, one lnmean and one f64 atomic more per path segment); not the headline number")
@@ -145,6 +146,14 @@ def main():
         if args.ski != SKI or args.source != "sersic":
             raise SystemExit("--config 3 selects its own ski file and source")
         args.ski = os.path.join(ROOT, "tests", "ski", "cfg3.ski")
+    if args.config == 5:
+        if args.ski != SKI or args.source != "sersic":
+            raise SystemExit("--config 5 selects its own ski file and source")
+        args.ski = os.path.join(ROOT, "tests", "ski", "cfg5.ski")
+        sitedir = tempfile.mkdtemp(prefix=f"bench_sites_r{rank}_")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_sites.py"), "--n", "100000", "--seed", "1",
+                               os.path.join(sitedir, "cfg5_sites.txt")])
+        os.environ["SKH_INPUT_PATH"] = sitedir
     if args.config == 4:
         if args.ski != SKI or args.source != "sersic":
             raise SystemExit("--config 4 selects its own ski file and source")
@@ -219,7 +228,18 @@ def main():
         launches = max(1, args.steps)
         V = counters["cell_visits"] / launches
         U = counters["detector_updates"] / launches
-        bytes_per_launch = 20.0 * V + 8.0 * U
+        bytes_per_visit = 20.0
+        if args.config == 5:
+            # Voronoi: a visit reads the cell's own record (site + density, 32 B) and, for each of its neighbours, the
+            # neighbour index (4 B) and the neighbour's site (24 B) -- VoronoiMeshSnapshot.cpp:1096-1150; the mean
+            # neighbour count is taken over the cells of the mesh (15.2 for tests/ski/cfg5.ski)
+            import ctypes as C
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from test_host_model import scene_head
+            g = scene_head(sim).grid
+            nbar = g.vnbr_start[g.num_cells] / g.num_cells
+            bytes_per_visit = 32.0 + 28.0 * nbar
+        bytes_per_launch = bytes_per_visit * V + 8.0 * U
         walk_ms_sum = sum(kernel_ms) / len(kernel_ms)
         mean_ms = sum(t["total_ms"] for t in timings) / len(timings)
         achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
@@ -243,17 +263,22 @@ def main():
                                     "BASELINE configs[2]: Sersic source, 953688-cell octree, panchromatic 0.1-10 micron, 50-bin "
                                     "wavelength grid, tabulated dust mix (2102-point opacity table)"
                                     if args.config == 3 else
+                                    "BASELINE configs[4]: Sersic source, VoronoiMeshSpatialGrid of 10^5 sites (tools/make_sites.py "
+                                    "--n 100000 --seed 1), panchromatic 0.1-10 micron, 20 bins, THREE FullInstruments 256^2"
+                                    if args.config == 5 else
                                     "BASELINE configs[3]: Sersic source, dust imported from 10^6 smoothed particles "
                                     "(tools/make_sph.py --n 1000000 --seed 1), 985979-cell density-policy octree")
-                                   + (", 0.55 micron" if args.config != 3 else "") + ", forced scattering, peel-off to one "
-                                   "FullInstrument 512^2 (components + statistics), " + os.path.relpath(args.ski, ROOT),
+                                   + (", 0.55 micron" if args.config not in (3, 5) else "") + ", forced scattering, peel-off"
+                                   + (" to one FullInstrument 512^2" if args.config != 5 else "")
+                                   + " (components + statistics), " + os.path.relpath(args.ski, ROOT),
                        "packets_per_step_per_gpu": P,
-                       "cells": 953688 if (args.ski == SKI or args.config == 3) else 985979 if args.config == 4 else None,
+                       "cells": 953688 if (args.ski == SKI or args.config == 3) else 985979 if args.config == 4
+                       else 100000 if args.config == 5 else None,
                        "store_radiation_field": bool(args.store_radiation_field),
                        "parallelism": f"history-range x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(P) if (args.ski == SKI and args.source == "sersic") else None,
-                         "kernel": "walkKernel<octree>: all launches of one step, overlapped on the slot groups' streams "
+                         "kernel": "walkKernel<" + ("Voronoi" if args.config == 5 else "octree") + ">: all launches of one step, overlapped on the slot groups' streams "
                                    "(denominator: segment_ms)",
                          "kernel_ms": mean_ms, "walk_kernel_ms_sum": walk_ms_sum,
                          "transition_kernel_ms": sum(t["transition_ms"] for t in timings) / len(timings),
@@ -261,7 +286,7 @@ def main():
                          "generations": sum(t["generations"] for t in timings) / len(timings),
                          "cell_visits_per_packet": V / P, "detector_updates_per_packet": U / P,
                          "rewalk_visits_per_packet": counters["rewalk_visits"] / launches / P,
-                         "algorithmic_bytes_per_packet": bytes_per_launch / P},
+                         "algorithmic_bytes_per_packet": bytes_per_launch / P, "algorithmic_bytes_per_visit": bytes_per_visit},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.ski if args.source == "sersic" else ski_path, os.environ.get("SKH_INPUT_PATH"))

@@ -16,6 +16,8 @@ Fixtures:
   cfg5small_*  reduced config 5 (tests/ski/cfg5small.ski): Voronoi grid with 1500 random sites, panchromatic, four
                instruments -> files, rays, cells (the host layer's tessellation is its own: the traversal is compared bit
                for bit, cell volumes to rounding, sampled densities and output files statistically)
+  cfg5_rays*   config 5 at full size (tests/ski/cfg5.ski, 10^5 Voronoi sites from tools/make_sites.py): 208 fixed rays and
+               the reference's (m, ds) sequences
   cfg4small_*  reduced config 4 (tests/ski/cfg4small.ski): dust imported from 3000 smoothed particles
                (tests/ski/cfg4small_sph.txt, made by tools/make_sph.py), 2x10^4 packets -> files, rays, cells
   *_rays.txt / *_rays_ref.txt   fixed rays and the reference's (m, ds) sequences (C99 hex floats)
@@ -102,6 +104,17 @@ def main():
                 dens.append(float.fromhex(t[5]))
             np.savez_compressed(os.path.join(HERE, name + "_cells.npz"), volume=np.array(vol), density=np.array(dens),
                                 mix=np.array(mix))
+    # config 5 at full size: only the traversal is pinned (10^5 Voronoi cells; the site file is regenerated, not committed)
+    if len(sys.argv) == 1 or "cfg5" in sys.argv[1:]:
+        with tempfile.TemporaryDirectory() as tmp:
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_sites.py"), "--n", "100000", "--seed", "1",
+                                   os.path.join(tmp, "cfg5_sites.txt")])
+            rayfile = os.path.join(HERE, "cfg5_rays.txt")
+            with open(rayfile, "w") as fh:
+                for r, k in rays(4000 * 3.08567758e16, 200, 5):
+                    fh.write(" ".join(float(v).hex() for v in list(r) + list(k)) + "\n")
+            subprocess.check_call([REF, "rays", os.path.join(ROOT, "tests", "ski", "cfg5.ski"), rayfile,
+                                   os.path.join(HERE, "cfg5_rays_ref.txt"), "-o", tmp], cwd=tmp, stdout=subprocess.DEVNULL)
     print("golden fixtures regenerated")
 
 

@@ -159,3 +159,50 @@ def _densities(sim):
     from test_host_model import scene_head
     head = scene_head(sim)
     return np.ctypeslib.as_array(head.medium.number_density, shape=(head.grid.num_cells,)).copy()
+
+
+def _ray_fixture(name):
+    rays = [[float.fromhex(t) for t in line.split()] for line in open(golden(name + "_rays.txt"))]
+    ref = open(golden(name + "_rays_ref.txt")).read().split("\n")
+    out, pos = [], 0
+    for i, ray in enumerate(rays):
+        head = ref[pos].split()
+        assert head[0] == "ray" and int(head[1]) == i
+        n = int(head[2])
+        k = np.array([float.fromhex(v) for v in head[3:6]])
+        m_ref = np.array([int(ref[pos + 1 + j].split()[0]) for j in range(n)], dtype=np.int32)
+        ds_ref = np.array([float.fromhex(ref[pos + 1 + j].split()[1]) for j in range(n)])
+        pos += 1 + n
+        out.append((np.array(ray[:3]), k, m_ref, ds_ref))
+    return out
+
+
+def config5_simulation(tmp_dir, num_packets=1000):
+    """tests/ski/cfg5.ski with its 10^5 Voronoi sites regenerated by tools/make_sites.py (deterministic)"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_sites.py"), "--n", "100000", "--seed", "1",
+                           os.path.join(str(tmp_dir), "cfg5_sites.txt")])
+    old = os.environ.get("SKH_INPUT_PATH")
+    os.environ["SKH_INPUT_PATH"] = str(tmp_dir)
+    try:
+        return Simulation(ski("cfg5.ski"), num_packets=num_packets).setup()
+    finally:
+        if old is None:
+            del os.environ["SKH_INPUT_PATH"]
+        else:
+            os.environ["SKH_INPUT_PATH"] = old
+
+
+def test_full_size_voronoi_rays_bit_exact(tmp_path):
+    """BASELINE configs[4] at full size: the host layer's own tessellation of 10^5 sites carries the reference's
+    (Voro++'s) paths -- 208 rays, 7339 segments, cell indices and lengths bit for bit"""
+    sim = config5_simulation(tmp_path)
+    total = 0
+    for r, k, m_ref, ds_ref in _ray_fixture("cfg5"):
+        m, ds = O.trace_ray(sim, r, k)
+        assert np.array_equal(m, m_ref)
+        assert np.array_equal(ds.view(np.uint64), ds_ref.view(np.uint64))
+        total += len(m_ref)
+    assert total > 7000
