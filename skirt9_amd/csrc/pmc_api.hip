@@ -247,13 +247,22 @@ namespace
             if (id < 0) return fail(PMC_ERR_INVALID, "cell without a leaf node");
             LeafRec& rec = T.leaves[m];
             rec.code = code(id);
+#if PMC_LEAF64
+            for (int a = 0; a < 3; ++a) rec.axis[a].density = density[m];
+#else
             rec.density = density[m];
+#endif
             for (int wall = 0; wall < 6; ++wall)
             {
                 const int axis = wall >> 1, side = wall & 1;
+                const int N = covering(id, wall);
+#if PMC_LEAF64
+                // the leaf across the wall (same size or coarser), or the same-size internal node (finer neighbours: the walk
+                // descends from it by the index bits of its position), or "outside"
+                rec.axis[axis].link[side] = linkOf(N);
+#else
                 const int t1 = axis == 0 ? 1 : 0;  // transverse axes, x before y before z
                 const int t2 = axis == 2 ? 1 : 2;
-                const int N = covering(id, wall);
                 for (int q = 0; q < 4; ++q)
                 {
                     uint32_t link;
@@ -269,6 +278,7 @@ namespace
                     }
                     rec.link[wall][q] = link;
                 }
+#endif
                 // the reference's neighbour list of this leaf, re-indexed by cell
                 T.nbrStart[6 * size_t(m) + wall] = (int32_t)T.nbrList.size();
                 for (int qq = g.nbr_start[6 * size_t(id) + wall]; qq < g.nbr_start[6 * size_t(id) + wall + 1]; ++qq)
@@ -620,10 +630,9 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     ctx->block = 256;
     int perCU = pmcWalkBlocksPerCU(D.grid_kind, ctx->block, ctx->walkLds);
     if (perCU < 1) perCU = 1;
-    // The walk kernel's throughput does not grow beyond two waves per SIMD (it is bound by instruction issue, see
-    // DESIGN.md), and a small footprint leaves room for the transition / launch kernels of the other slot group to
-    // run on the same CUs at the same time.
-    int wantPerCU = 2;
+    // Three workgroups per CU (three waves per SIMD at 149 VGPRs): measured best with the 64-byte cell records
+    // (profiles/README.md); the transition / launch kernels of the other slot group get the CUs between generations.
+    int wantPerCU = 3;
     if (const char* env = getenv("PMC_WALK_BLOCKS_PER_CU")) wantPerCU = std::max(1, atoi(env));  // tuning aid
     perCU = std::min(perCU, wantPerCU);
     ctx->grid = ctx->numCU * perCU;

@@ -30,6 +30,30 @@
 #define PMC_LINK_NODE 0x80000000u
 #define PMC_LINK_MAX_INDEX ((1u << 27) - 2u)
 
+#ifndef PMC_LEAF64
+    #define PMC_LEAF64 1  // 1: 64-byte cell records, ONE 16-byte gather per walk step; 0: 128-byte records, four links per wall
+#endif
+#if PMC_LEAF64
+// One 64-byte record (= one memory sector) per cell.  A walk step leaves the cell through a wall of ONE axis and needs
+// the cell's density and the link through that wall: both come with a single 16-byte gather of axis[a].  A link names
+// the leaf that covers the whole wall (same size or coarser), or the same-size internal node whose children share the
+// wall (finer neighbours): the walk then descends by the index bits of its position, one 4-byte gather per level.
+struct LeafRec
+{
+    struct
+    {
+        double   density;   // number density n[m] (the same in all three entries)
+        uint32_t link[2];   // through the lower / upper wall of this axis
+    } axis[3];
+    uint64_t code;          // box code: bits 0-19 / 20-39 / 40-59 = byte offsets of the lower x / y / z wall coordinate in the
+                            // LDS table [3][2^Lmax+1], bits 60-63 = size exponent e = Lmax - level
+    uint64_t pad;
+};
+static_assert(sizeof(LeafRec) == 64, "LeafRec must be one 64-byte record");
+#define PMC_LEAF_SHIFT 6
+#define PMC_LEAF_CODE_OFFSET 48
+#define PMC_LEAF_DENSITY(rec) ((rec).axis[0].density)
+#else
 struct LeafRec
 {
     uint64_t code;        // box code: bits 0-19 / 20-39 / 40-59 = byte offsets of the lower x / y / z wall coordinate in the
@@ -41,6 +65,10 @@ struct LeafRec
     int32_t  pad[4];
 };
 static_assert(sizeof(LeafRec) == 128, "LeafRec must be one 128-byte record");
+#define PMC_LEAF_SHIFT 7
+#define PMC_LEAF_CODE_OFFSET 0
+#define PMC_LEAF_DENSITY(rec) ((rec).density)
+#endif
 
 struct NodeRec
 {
