@@ -185,6 +185,12 @@ def main():
     eng = Engine(sim.scene, local_rank)
     frames = torch.zeros(sim.frame_size, dtype=torch.float64, device=f"cuda:{local_rank}")
     eng.bind_frames(frames.data_ptr(), frames.numel())
+    rf = None
+    if sim.radiation_field_size:
+        # the radiation field table in a torch tensor, so that the ranks can sum it onto ALL ranks over RCCL
+        # (MediumSystem::communicateRadiationField, MediumSystem.cpp:1304-1313)
+        rf = torch.zeros(sim.radiation_field_size, dtype=torch.float64, device=f"cuda:{local_rank}")
+        eng.bind_radiation_field(rf.data_ptr(), rf.numel())
     seed = sim.seed
 
     def step(index):
@@ -199,6 +205,9 @@ def main():
                 dist.reduce(frames, dst=0, op=dist.ReduceOp.SUM)
             if rank != 0:
                 frames.zero_()  # rank 0 holds the sum so far; the others start the next segment from zero
+            if rf is not None:
+                dist.all_reduce(rf, op=dist.ReduceOp.SUM)
+                rf.zero_()      # (a benchmark step is a whole segment: what follows would consume the field here)
 
     def fence():
         if world > 1:

@@ -6,6 +6,8 @@ include/pmc.h, against the CPU oracle (oracle/life_cycle.cpp) on the same scene.
   detector arrays agree to floating-point summation order and libm differences -- far tighter than Monte Carlo
   noise.  Tolerances are stated per test.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -154,3 +156,59 @@ def test_radiation_field_absent_unless_requested():
     assert eng.radiation_field_size == 0 and eng.radiation_field_device_ptr == 0
     with pytest.raises(RuntimeError, match="does not store"):
         eng.download_radiation_field()
+
+
+def _read_fits(path):
+    """primary image of a FITS file written by FITSInOut::write / the host layer: float32, big endian"""
+    raw = open(path, "rb").read()
+    cards = {}
+    pos = 0
+    while True:
+        card = raw[pos:pos + 80].decode("ascii")
+        pos += 80
+        if card.startswith("END"):
+            break
+        if "=" in card[:10]:
+            cards[card[:8].strip()] = card[10:].split("/")[0].strip()
+    pos = (pos + 2879) // 2880 * 2880
+    shape = [int(cards[f"NAXIS{i}"]) for i in range(int(cards["NAXIS"]), 0, -1)]
+    count = int(np.prod(shape))
+    return np.frombuffer(raw[pos:pos + 4 * count], dtype=">f4").astype(np.float64).reshape(shape)
+
+
+def test_fits_cube_within_noise_of_the_reference(tmp_path):
+    """north_star: 'FITS output within 1 sigma of the CPU reference at equal packet count'.  Config 1 with 10^6
+    packets on the GPU (Philox streams) against the files the UNMODIFIED reference wrote with its own generator
+    (tests/golden/cfg1_i0_*.fits): per pixel the difference of the total surface brightness is compared with the
+    Monte Carlo noise of both runs, sigma^2 = sigma_ref^2 + sigma_gpu^2 with sigma/F = R = sqrt(S2/S1^2 - 1/N) from each
+    run's own statistics cubes (sum of w and of w^2 per pixel).  Stated tolerances: reduced chi^2 over the well sampled
+    pixels within [0.85, 1.2] (1 expected), no pixel beyond 5.5 sigma, the integrated flux within 1 sigma x 3."""
+    n = 1000000
+    sim = Simulation(ski("cfg1.ski"), num_packets=n).setup()
+    eng = _engine(sim)
+    eng.run_primary(0, n, 20260929)
+    sim.write(eng.download(), str(tmp_path))
+
+    def cube(where, name):
+        return _read_fits(os.path.join(where, f"cfg1_i0_{name}.fits")).reshape(-1)
+
+    from conftest import golden
+    gold = os.path.dirname(golden("x"))
+    f_ref, f_gpu = cube(gold, "total"), cube(str(tmp_path), "total")
+    stats = {}
+    for tag, where in (("ref", gold), ("gpu", str(tmp_path))):
+        s0, s1, s2 = cube(where, "stats0"), cube(where, "stats1"), cube(where, "stats2")
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r2 = np.where(s1 > 0, s2 / s1 ** 2 - 1.0 / n, np.inf)
+        stats[tag] = (s0, np.sqrt(np.maximum(r2, 0)))
+    good = (stats["ref"][0] >= 30) & (stats["gpu"][0] >= 30)       # at least 30 contributing packets in both runs
+    assert good.sum() > 1000
+    with np.errstate(invalid="ignore"):
+        sigma = np.sqrt((stats["ref"][1] * f_ref) ** 2 + (stats["gpu"][1] * f_gpu) ** 2)
+    z = (f_gpu - f_ref)[good] / sigma[good]
+    chi2 = float(np.mean(z ** 2))
+    assert 0.85 <= chi2 <= 1.2, chi2
+    assert np.abs(z).max() < 5.5, float(np.abs(z).max())
+    # integrated flux: noise of the sum from the per-pixel variances
+    total_sigma = np.sqrt(np.sum(sigma[np.isfinite(sigma)] ** 2))
+    assert abs(f_gpu.sum() - f_ref.sum()) <= 3 * total_sigma
