@@ -181,7 +181,10 @@ def main():
         rf_ski = os.path.join(tempfile.mkdtemp(prefix=f"bench_rf_r{rank}_"), os.path.basename(ski_path))
         open(rf_ski, "w").write(text.replace('storeRadiationField="false"', 'storeRadiationField="true"'))
         ski_path = rf_ski
-    sim = Simulation(ski_path, num_packets=total_per_step).setup()
+    sim = Simulation(ski_path, num_packets=total_per_step)
+    if args.config == 4:
+        sim.use_device_sampler(local_rank)  # setup-time density sampling of the particle medium on this rank's GPU
+    sim.setup()
     eng = Engine(sim.scene, local_rank)
     frames = torch.zeros(sim.frame_size, dtype=torch.float64, device=f"cuda:{local_rank}")
     eng.bind_frames(frames.data_ptr(), frames.numel())

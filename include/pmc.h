@@ -22,6 +22,8 @@
  *                        MediumSystem.cpp:1294-1300) and MediumSystem::meanIntensity reads (:1370-1380);
  *   pmc_radiation_field_device <- same table as a device pointer, for the counterpart of
  *                        MediumSystem::communicateRadiationField (MediumSystem.cpp:1304-1313: sumToAll) as one RCCL all-reduce
+ *   pmc_sampler_*     <- ParticleSnapshot::density(Position) evaluated for the sample positions of the setup phase
+ *                        (ParticleSnapshot.cpp:233-243; DensityTreePolicy.cpp:141, MediumSystem.cpp:91-96)
  *   pmc_counters      <- no reference counterpart: counted cell visits / detector updates for the roofline
  *
  * Conventions: plain C, no exceptions cross the boundary; every function returns PMC_OK (0) or a negative
@@ -288,6 +290,35 @@ int pmc_set_num_slots(pmc_ctx* ctx, int64_t num_slots);
    its transition + launch kernel launches, and the number of generations (walk, transition, launch kernel triples,
    counted over all slot groups) */
 int pmc_last_timing(pmc_ctx* ctx, float* total_ms, float* walk_ms, float* transition_ms, int32_t* generations);
+
+/* ---------------------------------------------------------------- setup: density of a smoothed-particle medium ---- */
+
+/* ParticleSnapshot::density(Position) (SKIRT/core/ParticleSnapshot.cpp:233-243) for MANY positions at once: the setup
+   phase of an imported medium evaluates it 100 times per tree node and per cell (DensityTreePolicy.cpp:141,
+   MediumSystem.cpp:91-96).  density = sum over the particles listed for the block of the position, IN LIST ORDER, of
+   kernel(|r - r_i| / h_i) * rho_i with rho_i = M_i / h_i^3; block lookup as BoxSearch::entitiesFor(Vec)
+   (SKIRT/utils/BoxSearch.cpp:14-52,124-135: NR::locateClip on the three separation arrays).  With the cubic-spline
+   and uniform kernels the result equals the host evaluation bit for bit (no transcendental function on the way). */
+enum { PMC_KERNEL_CUBIC_SPLINE = 1, PMC_KERNEL_UNIFORM = 2 };
+
+typedef struct pmc_particles
+{
+    int32_t        kernel;         /* PMC_KERNEL_* */
+    int64_t        num_particles;
+    const double*  particle;       /* [num_particles][5]: x, y, z, h, rho = M / h^3 */
+    int32_t        num_blocks;     /* blocks per axis of the search grid */
+    const double*  xgrid;          /* num_blocks + 1 separation points per axis (first -inf, last +inf) */
+    const double*  ygrid;
+    const double*  zgrid;
+    const int64_t* block_start;    /* num_blocks^3 + 1; block b = (i*n + j)*n + k */
+    const int32_t* block_list;     /* particle indices */
+} pmc_particles;
+
+typedef struct pmc_sampler pmc_sampler;
+int  pmc_sampler_create(const pmc_particles* particles, int32_t device, pmc_sampler** out);
+/* positions: host array [n][3]; density: host array [n] (mass or number density as the particle weights imply) */
+int  pmc_sampler_density(pmc_sampler* sampler, const double* positions, int64_t n, double* density);
+void pmc_sampler_destroy(pmc_sampler* sampler);
 
 #ifdef __cplusplus
 }

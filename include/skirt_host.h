@@ -24,6 +24,10 @@ void skh_free(skh_simulation* sim);
 /* overrides applied before skh_setup */
 int skh_set_num_packets(skh_simulation* sim, uint64_t n);
 int skh_set_tree_topology_file(skh_simulation* sim, const char* treetop_path);
+/* before skh_setup: evaluate the densities of an imported particle medium (ParticleMedium) on the GPU during setup.  The
+   four pointers are libpmc.so's pmc_sampler_create, pmc_sampler_density, pmc_sampler_destroy and pmc_last_error (passed
+   at run time so that this library does not link against the HIP engine); results are bit-identical to the host's */
+int skh_set_particle_sampler(skh_simulation* sim, void* create, void* density, void* destroy, void* last_error, int32_t device);
 /* Simulation::setupSimulation */
 int skh_setup(skh_simulation* sim);
 /* valid after skh_setup, owned by the simulation */

@@ -50,6 +50,16 @@ namespace
     }
 }
 
+// error text of the calling thread, for the other translation units of the library (pmc_sampler.hip)
+void pmcSetError(const std::string& message)
+{
+    t_error = message;
+}
+
+namespace
+{
+}
+
 #define HIP_TRY(call)                                           \
     do                                                          \
     {                                                           \

@@ -19,7 +19,8 @@ SYMBOLS = ["pmc_abi_version", "pmc_last_error", "pmc_frame_layout_of", "pmc_crea
            "pmc_clear_frames", "pmc_run_primary", "pmc_sync", "pmc_download", "pmc_frames_device", "pmc_frames_size",
            "pmc_last_kernel_ms", "pmc_counters", "pmc_reset_counters", "pmc_trace_ray", "pmc_set_launch",
            "pmc_set_num_slots", "pmc_last_timing", "pmc_radiation_field_size", "pmc_radiation_field_device",
-           "pmc_download_radiation_field", "pmc_clear_radiation_field", "pmc_bind_radiation_field"]
+           "pmc_download_radiation_field", "pmc_clear_radiation_field", "pmc_bind_radiation_field", "pmc_sampler_create",
+           "pmc_sampler_density", "pmc_sampler_destroy"]
 
 _lib = None
 

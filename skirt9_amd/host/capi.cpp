@@ -54,6 +54,28 @@ int skh_set_num_packets(skh_simulation* h, uint64_t n)
     return 0;
 }
 
+// Hands the entry points of the device sampler (include/pmc.h: pmc_sampler_create / _density / _destroy, pmc_last_error)
+// to the simulation: the densities of an imported particle medium are then evaluated on the GPU during skh_setup.
+int skh_set_particle_sampler(skh_simulation* h, void* create, void* density, void* destroy, void* last_error, int32_t device)
+{
+    try
+    {
+        if (!h || !h->sim || !create || !density || !destroy) throw std::runtime_error("invalid argument");
+        skh::ParticleSamplerApi api;
+        api.create = reinterpret_cast<int (*)(const pmc_particles*, int32_t, pmc_sampler**)>(create);
+        api.density = reinterpret_cast<int (*)(pmc_sampler*, const double*, int64_t, double*)>(density);
+        api.destroy = reinterpret_cast<void (*)(pmc_sampler*)>(destroy);
+        api.lastError = reinterpret_cast<const char* (*)()>(last_error);
+        api.device = device;
+        h->sim->setParticleSampler(api);
+        return 0;
+    }
+    catch (const std::exception& e)
+    {
+        return fail(e);
+    }
+}
+
 int skh_set_tree_topology_file(skh_simulation* h, const char* path)
 {
     try

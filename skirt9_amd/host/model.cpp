@@ -445,10 +445,7 @@ namespace skh
                     if (node.level >= minLevel && node.level < maxLevel)
                         for (int i = 0; i != numDensitySamples; ++i) pos.push_back(random.position(node.box));
                 }
-                rhov.resize(pos.size());
-                parallelFor(pos.size(), [&](size_t b, size_t e) {
-                    for (size_t i = b; i != e; ++i) rhov[i] = medium.massDensity(pos[i]);
-                });
+                medium.massDensities(pos, rhov);
                 size_t at = 0;
                 for (size_t l = b0; l != b1; ++l)
                 {

@@ -167,6 +167,22 @@ namespace skh
         virtual double massDensity(Vec3 r) const = 0;
         virtual double totalMass() const = 0;
         virtual double totalNumber() const = 0;
+        // many positions at once (the setup phase samples 100 per tree node and per cell): on the host cores by
+        // default; a medium may hand the batch to the GPU
+        virtual void massDensities(const std::vector<Vec3>& positions, std::vector<double>& out) const
+        {
+            out.resize(positions.size());
+            parallelFor(positions.size(), [&](size_t b, size_t e) {
+                for (size_t i = b; i != e; ++i) out[i] = massDensity(positions[i]);
+            });
+        }
+        virtual void numberDensities(const std::vector<Vec3>& positions, std::vector<double>& out) const
+        {
+            out.resize(positions.size());
+            parallelFor(positions.size(), [&](size_t b, size_t e) {
+                for (size_t i = b; i != e; ++i) out[i] = numberDensity(positions[i]);
+            });
+        }
         // wavelength that the medium's normalisation adds to the simulation wavelengths (0: none)
         virtual double normalizationWavelength() const { return 0.; }
     };
@@ -231,6 +247,18 @@ namespace skh
             double result = snapshot.mass();
             if (!snapshot.holdsNumber()) result /= mix->mass();
             return result;
+        }
+        void massDensities(const std::vector<Vec3>& positions, std::vector<double>& out) const override
+        {
+            snapshot.densities(positions, out);
+            if (snapshot.holdsNumber())
+                for (double& v : out) v *= mix->mass();
+        }
+        void numberDensities(const std::vector<Vec3>& positions, std::vector<double>& out) const override
+        {
+            snapshot.densities(positions, out);
+            if (!snapshot.holdsNumber())
+                for (double& v : out) v /= mix->mass();
         }
     };
 

@@ -184,6 +184,18 @@ namespace skh
         return _listv[blockIndex(i, j, k)];
     }
 
+    void BoxSearch::flatten(std::vector<int64_t>& start, std::vector<int32_t>& list) const
+    {
+        start.assign(_listv.size() + 1, 0);
+        list.clear();
+        for (size_t b = 0; b != _listv.size(); ++b)
+        {
+            start[b] = static_cast<int64_t>(list.size());
+            list.insert(list.end(), _listv[b].begin(), _listv[b].end());
+        }
+        start[_listv.size()] = static_cast<int64_t>(list.size());
+    }
+
     size_t BoxSearch::numReferences() const
     {
         size_t n = 0;
@@ -368,6 +380,58 @@ namespace skh
                 return Box(p.x - p.h, p.y - p.h, p.z - p.h, p.x + p.h, p.y + p.h, p.z + p.h);
             },
             [this](int m, const Box& box) { return boxIntersectsSphere(box, _pv[m].x, _pv[m].y, _pv[m].z, _pv[m].h); });
+
+        // ---- optional: the same evaluation on the MI355X (include/pmc.h pmc_sampler_*)
+        if (_api.create && !_pv.empty())
+        {
+            pmc_particles P{};
+            if (_kernel->type() == "CubicSplineSmoothingKernel")
+                P.kernel = PMC_KERNEL_CUBIC_SPLINE;
+            else if (_kernel->type() == "UniformSmoothingKernel")
+                P.kernel = PMC_KERNEL_UNIFORM;
+            else
+                throw std::runtime_error("device density sampler: " + _kernel->type()
+                                         + " evaluates a transcendental function and would not be bit-identical; use the host");
+            std::vector<double> table(5 * _pv.size());
+            for (size_t m = 0; m != _pv.size(); ++m)
+            {
+                table[5 * m] = _pv[m].x, table[5 * m + 1] = _pv[m].y, table[5 * m + 2] = _pv[m].z, table[5 * m + 3] = _pv[m].h;
+                table[5 * m + 4] = _pv[m].density();
+            }
+            std::vector<int64_t> start;
+            std::vector<int32_t> list;
+            _search.flatten(start, list);
+            P.num_particles = static_cast<int64_t>(_pv.size());
+            P.particle = table.data();
+            P.num_blocks = _search.numBlocks();
+            P.xgrid = _search.xgrid().data(), P.ygrid = _search.ygrid().data(), P.zgrid = _search.zgrid().data();
+            P.block_start = start.data();
+            P.block_list = list.data();
+            if (_api.create(&P, _api.device, &_sampler) != 0)
+                throw std::runtime_error(std::string("device density sampler: ") + (_api.lastError ? _api.lastError() : "create failed"));
+        }
+    }
+
+    ParticleSnapshot::~ParticleSnapshot()
+    {
+        if (_sampler && _api.destroy) _api.destroy(_sampler);
+    }
+
+    void ParticleSnapshot::densities(const std::vector<Vec3>& positions, std::vector<double>& out) const
+    {
+        out.resize(positions.size());
+        if (positions.empty()) return;
+        if (_sampler)
+        {
+            static_assert(sizeof(Vec3) == 3 * sizeof(double), "Vec3 must be three packed doubles");
+            if (_api.density(_sampler, reinterpret_cast<const double*>(positions.data()), static_cast<int64_t>(positions.size()), out.data())
+                != 0)
+                throw std::runtime_error(std::string("device density sampler: ") + (_api.lastError ? _api.lastError() : "failed"));
+            return;
+        }
+        parallelFor(positions.size(), [&](size_t b, size_t e) {
+            for (size_t i = b; i != e; ++i) out[i] = density(positions[i]);
+        });
     }
 
     double ParticleSnapshot::density(Vec3 r) const

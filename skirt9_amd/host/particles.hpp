@@ -13,6 +13,7 @@
 #ifndef SKH_PARTICLES_HPP
 #define SKH_PARTICLES_HPP
 
+#include "../../include/pmc.h"
 #include "mathutil.hpp"
 #include <memory>
 #include <string>
@@ -39,6 +40,11 @@ namespace skh
         int numBlocks() const { return _numBlocks; }
         const Box& extent() const { return _extent; }
         size_t numReferences() const;
+        // flattened: separation arrays and the per-block lists as CSR (block b = (i*n + j)*n + k)
+        const Array& xgrid() const { return _xgrid; }
+        const Array& ygrid() const { return _ygrid; }
+        const Array& zgrid() const { return _zgrid; }
+        void flatten(std::vector<int64_t>& start, std::vector<int32_t>& list) const;
 
     private:
         int blockIndex(int i, int j, int k) const { return ((i * _numBlocks) + j) * _numBlocks + k; }
@@ -60,9 +66,21 @@ namespace skh
         bool isDust{true};
     };
 
+    // entry points of the device sampler (include/pmc.h pmc_sampler_*), handed over at run time so that this library
+    // keeps no link-time dependency on the HIP engine
+    struct ParticleSamplerApi
+    {
+        int (*create)(const pmc_particles*, int32_t, pmc_sampler**){nullptr};
+        int (*density)(pmc_sampler*, const double*, int64_t, double*){nullptr};
+        void (*destroy)(pmc_sampler*){nullptr};
+        const char* (*lastError)(){nullptr};
+        int32_t device{0};
+    };
+
     class ParticleSnapshot
     {
     public:
+        ~ParticleSnapshot();
         struct Particle
         {
             double x, y, z, h, M;
@@ -71,6 +89,11 @@ namespace skh
         // reads the file and builds the search grid; throws std::runtime_error on malformed input
         void load(const ParticleImportOptions& options, std::unique_ptr<SmoothingKernel> kernel);
         double density(Vec3 r) const;  // ParticleSnapshot.cpp:233-243
+        // the same for many positions: on the MI355X if a device sampler has been set (bit-identical results for the
+        // cubic-spline and uniform kernels), otherwise on the host cores
+        void densities(const std::vector<Vec3>& positions, std::vector<double>& out) const;
+        void useDeviceSampler(const ParticleSamplerApi& api) { _api = api; }
+        bool onDevice() const { return _sampler != nullptr; }
         double mass() const { return _mass; }
         bool holdsNumber() const { return _holdsNumber; }
         size_t numParticles() const { return _pv.size(); }
@@ -84,6 +107,8 @@ namespace skh
         std::unique_ptr<SmoothingKernel> _kernel;
         double _mass{0};
         bool _holdsNumber{false};
+        ParticleSamplerApi _api;
+        pmc_sampler* _sampler{nullptr};
     };
 
     // column text file (TextInFile): "# column N: description (unit)" header lines are optional; without them every

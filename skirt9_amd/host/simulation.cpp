@@ -531,6 +531,7 @@ namespace skh
 
         // ---- dust mix, medium normalisation
         _medium->mix->setup(rangeMin, rangeMax, std::vector<double>(simWavelengths.begin(), simWavelengths.end()));
+        if (auto pm = dynamic_cast<ParticleMedium*>(_medium.get())) pm->snapshot.useDeviceSampler(_samplerApi);
         _medium->setup();
 
         // ---- spatial grid (tree construction draws from the random stream) then cell densities
@@ -567,10 +568,7 @@ namespace skh
                 {
                     for (int n = 0; n != _numDensitySamples; ++n) pos.push_back(_grid->randomPositionInCell(m, _random));
                 }
-                samples.resize(pos.size());
-                parallelFor(pos.size(), [&](size_t b, size_t e) {
-                    for (size_t i = b; i != e; ++i) samples[i] = _medium->numberDensity(pos[i]);
-                });
+                _medium->numberDensities(pos, samples);
                 size_t at = 0;
                 for (int m = m0; m != m1; ++m)
                 {

@@ -58,6 +58,9 @@ namespace skh
 
         // optional overrides applied before setup()
         void setNumPackets(uint64_t n) { _numPackets = n; }
+        // evaluate the densities of an imported particle medium on the GPU during setup (include/pmc.h pmc_sampler_*);
+        // ignored for other media
+        void setParticleSampler(const ParticleSamplerApi& api) { _samplerApi = api; }
         void setTreeTopology(std::vector<char> topology) { _topology = std::move(topology); }
 
     private:
@@ -67,6 +70,7 @@ namespace skh
 
         std::string _prefix;
         std::string _inputPath{"."};
+        ParticleSamplerApi _samplerApi;
         OutputUnits _units;
         int _seed{0};
         Random _random;
