@@ -1,6 +1,6 @@
 // main.cpp -- command line driver: runs an unchanged SKIRT ski file with the primary-emission loop on the MI355X.
 //
-//   skirt_mi355x [-o outdir] [-g device] [-n packets] file.ski
+//   skirt_mi355x [-o outdir] [-g device] [-n packets] [-s] file.ski     (-s: particle-medium densities sampled on the GPU)
 //
 // Counterpart of SKIRT/main (SkirtCommandLineHandler.cpp:295-372 doSimulation): construct the simulation from the
 // ski file, set it up, run the primary emission segment (here: on the GPU through the C ABI of include/pmc.h),
@@ -20,9 +20,15 @@ int main(int argc, char** argv)
     std::string outdir = ".", ski;
     int device = 0;
     unsigned long long packets = 0;
+    bool deviceSetup = false;
     for (int i = 1; i < argc; ++i)
     {
-        if (!strcmp(argv[i], "-o") && i + 1 < argc)
+        if (!strcmp(argv[i], "-s"))
+        {
+            deviceSetup = true;  // sample the densities of an imported particle medium on the GPU during setup
+            continue;
+        }
+        else if (!strcmp(argv[i], "-o") && i + 1 < argc)
             outdir = argv[++i];
         else if (!strcmp(argv[i], "-g") && i + 1 < argc)
             device = atoi(argv[++i]);
@@ -33,7 +39,7 @@ int main(int argc, char** argv)
     }
     if (ski.empty())
     {
-        fprintf(stderr, "usage: skirt_mi355x [-o outdir] [-g device] [-n packets] file.ski\n");
+        fprintf(stderr, "usage: skirt_mi355x [-o outdir] [-g device] [-n packets] [-s] file.ski\n");
         return 2;
     }
     using clock = std::chrono::steady_clock;
@@ -46,6 +52,14 @@ int main(int argc, char** argv)
         return 1;
     }
     if (packets) skh_set_num_packets(sim, packets);
+    if (deviceSetup
+        && skh_set_particle_sampler(sim, reinterpret_cast<void*>(&pmc_sampler_create), reinterpret_cast<void*>(&pmc_sampler_density),
+                                    reinterpret_cast<void*>(&pmc_sampler_destroy), reinterpret_cast<void*>(&pmc_last_error), device)
+               != 0)
+    {
+        fprintf(stderr, "Fatal error: %s\n", skh_last_error());
+        return 1;
+    }
     auto t0 = clock::now();
     printf("Starting setup...\n");
     if (skh_setup(sim) != 0)
