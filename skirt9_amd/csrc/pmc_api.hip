@@ -478,6 +478,22 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if ((rc = ctx->upload(rec.data(), rec.size(), &D.vsite))) return bail(rc);
         if ((rc = ctx->upload(g.vnbr_start, size_t(g.num_cells) + 1, &D.vnbr_start))) return bail(rc);
         if ((rc = ctx->upload(g.vnbr_list, size_t(g.vnbr_start[g.num_cells]), &D.vnbr_list))) return bail(rc);
+        {
+            const size_t np = size_t(g.vnbr_start[g.num_cells]);
+            std::vector<double> pair(4 * np, 0.);
+            for (size_t q = 0; q < np; ++q)
+            {
+                const int mi = g.vnbr_list[q];
+                if (mi >= 0)
+                {
+                    pair[4 * q] = g.site[3 * size_t(mi)], pair[4 * q + 1] = g.site[3 * size_t(mi) + 1];
+                    pair[4 * q + 2] = g.site[3 * size_t(mi) + 2];
+                }
+                const long long bits = mi;
+                std::memcpy(&pair[4 * q + 3], &bits, sizeof(double));
+            }
+            if ((rc = ctx->upload(pair.data(), pair.size(), &D.vpair))) return bail(rc);
+        }
         D.vblock_n = g.vblock_n;
         if ((rc = ctx->upload(g.vblock_start, nb3 + 1, &D.vblock_start))) return bail(rc);
         if ((rc = ctx->upload(g.vblock_list, size_t(g.vblock_start[nb3]), &D.vblock_list))) return bail(rc);

@@ -179,6 +179,9 @@ struct DevScene
     const double* vsite;          // [num_cells][4]
     const int32_t* vnbr_start;    // [num_cells + 1]
     const int32_t* vnbr_list;
+    const double* vpair;          // [vnbr_start[num_cells]][4]: per (cell, neighbour) entry the neighbour's site x, y, z and its
+                                  // index (as the bit pattern of an int64), in list order: the hot loop reads two 16-byte
+                                  // words per neighbour from consecutive addresses instead of index -> site gathers
     int32_t vblock_n;
     const int32_t* vblock_start;  // [vblock_n^3 + 1]
     const int32_t* vblock_list;

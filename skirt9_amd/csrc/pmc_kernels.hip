@@ -61,6 +61,12 @@
 #ifndef PMC_TRANSITION_MIN_WAVES
     #define PMC_TRANSITION_MIN_WAVES 1  // likewise for the transition and launch kernels
 #endif
+#ifndef PMC_VORO_PAIRS
+    #define PMC_VORO_PAIRS 1  // Voronoi walk reads the per-(cell, neighbour) table DevScene::vpair instead of index -> site
+#endif
+#ifndef PMC_VORO_UNROLL
+    #define PMC_VORO_UNROLL 8  // Voronoi walk: neighbours whose gathers are in flight together (pmc_walk.inc voroEnter)
+#endif
 #ifndef PMC_WALK_STEPS
     #define PMC_WALK_STEPS 4  // steps between two service checks
 #endif
