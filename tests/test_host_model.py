@@ -231,3 +231,73 @@ def test_mean_file_dust_mix_equals_listed_values(tmp_path):
         x = np.ctypeslib.as_array(getattr(a, field), shape=(a.num_lambda,))
         y = np.ctypeslib.as_array(getattr(b, field), shape=(b.num_lambda,))
         assert np.allclose(x, y, rtol=1e-14, atol=0), field
+
+
+# ---------------------------------------------------------------- Voronoi tessellation (config 5)
+
+def _voronoi_sim(tmp_path, sites):
+    """cfg5small.ski with its random sites replaced by the given ones (policy File)"""
+    text = open(ski("cfg5small.ski")).read().replace('policy="Uniform" numSites="1500"', 'policy="File" filename="sites.txt"')
+    (tmp_path / "sites.txt").write_text("".join("%.17g %.17g %.17g\n" % tuple(s) for s in sites))
+    (tmp_path / "v.ski").write_text(text)
+    return Simulation(str(tmp_path / "v.ski")).setup()
+
+
+def _voronoi_tables(sim):
+    g = scene_head(sim).grid
+    n = g.num_cells
+    start = np.ctypeslib.as_array(g.vnbr_start, shape=(n + 1,)).copy()
+    nbr = np.ctypeslib.as_array(g.vnbr_list, shape=(start[n],)).copy()
+    site = np.ctypeslib.as_array(g.site, shape=(n, 3)).copy()
+    return n, start, nbr, site
+
+
+@pytest.mark.parametrize("kind", ["random", "lattice", "clustered"])
+def test_voronoi_tessellation_is_consistent(tmp_path, kind):
+    """the host layer's own Voronoi construction (skirt9_amd/host/voronoi.cpp): sites come out in the reference's order
+    (sorted by x, VoronoiMeshSnapshot.cpp:509); neighbour relations are symmetric; every wall of the domain is touched;
+    a cell's neighbours are exactly the sites that a dense set of its bisector mid-points confirms -- also for a regular
+    lattice (maximally degenerate: eight cells meet in every vertex) and for strongly clustered sites"""
+    rng = np.random.default_rng(5)
+    pc = 3.08567758e16
+    half = np.array([20000.0, 20000.0, 4000.0])
+    if kind == "random":
+        sites = (rng.random((800, 3)) - 0.5) * 2 * half * 0.999
+    elif kind == "lattice":
+        ax = [np.linspace(-h, h, 9)[:-1] + h / 8 for h in half]
+        sites = np.array([[x, y, z] for x in ax[0] for y in ax[1] for z in ax[2]])
+    else:
+        sites = np.concatenate([rng.normal(0, 300.0, (600, 3)), (rng.random((200, 3)) - 0.5) * 2 * half * 0.999])
+        sites = sites[np.all(np.abs(sites) < half * 0.999, axis=1)]
+    sim = _voronoi_sim(tmp_path, sites)
+    n, start, nbr, site = _voronoi_tables(sim)
+    assert n == len(sites)
+    assert np.all(np.diff(site[:, 0]) >= 0)                      # the reference's order
+    assert np.allclose(np.sort(site[:, 0]), np.sort(sites[:, 0] * pc), rtol=1e-15)
+    lists = [set(nbr[start[m]:start[m + 1]].tolist()) for m in range(n)]
+    assert all(len(l) >= 4 for l in lists)
+    asym = sum(1 for m in range(n) for j in lists[m] if j >= 0 and m not in lists[j])
+    assert asym == 0
+    assert set(range(-6, 0)) <= set(nbr.tolist())
+    interior = [m for m in range(n) if min(lists[m]) >= 0]
+    assert len(interior) > 50
+    if kind == "lattice":
+        # the six face neighbours of an interior lattice cell (at one lattice spacing along an axis) must be present
+        spacing = 2 * half / 8 * pc
+        for m in interior:
+            found = 0
+            for j in lists[m]:
+                d = np.abs(site[j] - site[m])
+                if np.sum(d > 1e-6 * spacing.max()) == 1 and np.any(np.isclose(d, spacing, rtol=1e-9)):
+                    found += 1
+            assert found == 6, (m, found)
+    else:
+        # independent construction: the Delaunay neighbours (Qhull) of an interior cell are its Voronoi neighbours
+        from scipy.spatial import Delaunay
+        tri = Delaunay(site / pc)
+        indptr, indices = tri.vertex_neighbor_vertices
+        for m in interior:
+            qhull = set(indices[indptr[m]:indptr[m + 1]].tolist())
+            assert lists[m] <= qhull, (m, lists[m] - qhull)
+            # Qhull may list neighbours through faces of vanishing area (co-spherical sites): at most a few
+            assert len(qhull - lists[m]) <= 2, (m, qhull - lists[m])
