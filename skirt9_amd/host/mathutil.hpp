@@ -257,6 +257,17 @@ namespace skh
             double z = uniform();
             return box.fracPos(x, y, z);
         }
+        // Random::direction() (Random.cpp:121-126) with Direction(theta, phi) (Direction.cpp:11-38)
+        Vec3 direction()
+        {
+            double theta = acos(2.0 * uniform() - 1.0);
+            double phi = 2.0 * M_PI * uniform();
+            const double eps = 1e-8;
+            if (theta <= eps) return Vec3{0, 0, 1};
+            if (theta >= M_PI - eps) return Vec3{0, 0, -1};
+            double sintheta = sin(theta);
+            return Vec3{sintheta * cos(phi), sintheta * sin(phi), cos(theta)};
+        }
         int seed() const { return _seed; }
         unsigned long long draws() const { return _draws; }
 

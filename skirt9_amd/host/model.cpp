@@ -170,6 +170,73 @@ namespace skh
         return 2.0 * _rho0 * _hz;
     }
 
+    namespace
+    {
+        // SpecialFunctions::LambertW1 (SKIRT/utils/SpecialFunctions.cpp:578-625)
+        double lambertW1(double z)
+        {
+            const double eps = 1.0e-12;
+            const double em1 = 0.3678794411714423215955237701614608;
+            static const double c[12] = {-1.0,
+                                         2.331643981597124203363536062168,
+                                         -1.812187885639363490240191647568,
+                                         1.936631114492359755363277457668,
+                                         -2.353551201881614516821543561516,
+                                         3.066858901050631912893148922704,
+                                         -4.175335600258177138854984177460,
+                                         5.858023729874774148815053846119,
+                                         -8.401032217523977370984161688514,
+                                         12.250753501314460424,
+                                         -18.100697012472442755,
+                                         27.029044799010561650};
+            if (z < -em1 || z > 0.0 || std::isinf(z) || std::isnan(z)) throw std::runtime_error("LambertW1: bad argument");
+            if (z == 0.0) return -DBL_MAX;
+            double q = z + em1;
+            double r = -sqrt(q);
+            double t8 = c[8] + r * (c[9] + r * (c[10] + r * c[11]));
+            double t5 = c[5] + r * (c[6] + r * (c[7] + r * t8));
+            double t1 = c[1] + r * (c[2] + r * (c[3] + r * (c[4] + r * t5)));
+            double w0 = c[0] + r * t1;
+            if (q < 3.0e-3) return w0;
+            double w, e, p, t;
+            if (z < -1e-6)
+                w = w0;
+            else
+            {
+                double l1 = log(-z);
+                double l2 = log(-l1);
+                w = l1 - l2 + l2 / l1;
+            }
+            for (int i = 0; i < 10; i++)
+            {
+                e = exp(w);
+                t = w * e - z;
+                p = w + 1.0;
+                t /= e * p - 0.5 * (p + 1.0) * t / p;
+                w -= t;
+                if (fabs(t) < eps * (1.0 + fabs(w))) return w;
+            }
+            throw std::runtime_error("LambertW1: no convergence");
+        }
+    }
+    Vec3 ExpDiskGeometry::generatePosition(Random& random) const
+    {
+        double R, X;
+        do
+        {
+            X = random.uniform();
+            R = _hR * (-1.0 - lambertW1((X - 1.0) / M_E));
+        } while ((_Rmax > 0.0 && R >= _Rmax) || R <= _Rmin);
+        double phi = 2.0 * M_PI * random.uniform();
+        double z;
+        do
+        {
+            X = random.uniform();
+            z = (X <= 0.5) ? _hz * log(2.0 * X) : -_hz * log(2.0 * (1.0 - X));
+        } while (_zmax > 0.0 && fabs(z) >= _zmax);
+        return Vec3{R * cos(phi), R * sin(phi), z};  // Position(R, phi, z, CYLINDRICAL)
+    }
+
     // SersicGeometry.cpp:21-52
     SersicGeometry::SersicGeometry(double reff, double n) : _reff(reff), _n(n)
     {
@@ -188,6 +255,13 @@ namespace skh
         return 1.0 / (_reff * _reff) * pow(_b, 2.0 * _n) / (2.0 * M_PI * special::gamma(2.0 * _n + 1.0));
     }
 
+    Vec3 SersicGeometry::generatePosition(Random& random) const
+    {
+        double r = _reff * _function->inverseMass(random.uniform());  // SersicGeometry::randomRadius
+        Vec3 k = random.direction();
+        return Vec3{r * k.x, r * k.y, r * k.z};  // Position(r, bfk)
+    }
+
     // PlummerGeometry.cpp:12-38
     PlummerGeometry::PlummerGeometry(double c) : _c(c) { _rho0 = 0.75 / pow(_c, 3) / M_PI; }
     double PlummerGeometry::density(Vec3 r) const
@@ -197,6 +271,13 @@ namespace skh
         return _rho0 * pow(1.0 + s * s, -2.5);
     }
     double PlummerGeometry::Sigmar() const { return 0.5 / (M_PI * _c * _c); }
+    Vec3 PlummerGeometry::generatePosition(Random& random) const
+    {
+        double t = pow(random.uniform(), 1.0 / 3.0);
+        double r = _c * t / sqrt((1.0 - t) * (1.0 + t));
+        Vec3 k = random.direction();
+        return Vec3{r * k.x, r * k.y, r * k.z};
+    }
 
     // ================================================================ DustMix (DustMix.cpp:47-162)
 
@@ -490,10 +571,22 @@ namespace skh
 
     // ================================================================ VoronoiSpatialGrid
 
-    void VoronoiSpatialGrid::setup(Random& random)
+    void VoronoiSpatialGrid::setup(Random& random, const Medium& medium)
     {
         std::vector<Vec3> sites;
-        if (policy == "Uniform")
+        if (policy == "DustDensity")
+        {
+            // VoronoiMeshSpatialGrid.cpp:22-40,73-85 (sampleMedia with ONE dust medium: the uniform deviate that selects
+            // the medium is consumed all the same), positions outside the domain are discarded
+            sites.resize(numSites);
+            for (int m = 0; m != numSites;)
+            {
+                (void)random.uniform();  // NR::locateClip(Xv, uniform) with Xv = {0, 1}
+                Vec3 p = medium.generatePosition(random);
+                if (extent.contains(p.x, p.y, p.z)) sites[m++] = p;
+            }
+        }
+        else if (policy == "Uniform")
         {
             // VoronoiMeshSpatialGrid.cpp:49-55: numSites positions from the simulation's random stream
             sites.resize(numSites);

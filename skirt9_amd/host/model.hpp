@@ -51,6 +51,8 @@ namespace skh
         virtual double SigmaX() const = 0;
         virtual double SigmaY() const = 0;
         virtual double SigmaZ() const = 0;
+        // Geometry::generatePosition: a random position drawn from the density (consumes the simulation's random stream)
+        virtual Vec3 generatePosition(Random& random) const = 0;
     };
 
     // SKIRT/utils/SersicFunction.cpp:13-101
@@ -76,6 +78,7 @@ namespace skh
         double SigmaX() const override;
         double SigmaY() const override;
         double SigmaZ() const override;
+        Vec3 generatePosition(Random& random) const override { return random.position(_box); }  // UniformBoxGeometry.cpp:37-40
         const Box& box() const { return _box; }
 
     private:
@@ -93,6 +96,7 @@ namespace skh
         double SigmaY() const override { return 2.0 * SigmaR(); }
         double SigmaZ() const override;
         double SigmaR() const;
+        Vec3 generatePosition(Random& random) const override;  // SepAxGeometry.cpp:11-19, ExpDiskGeometry.cpp:46-68
 
     private:
         double _hR, _hz, _Rmin, _Rmax, _zmax, _rho0;
@@ -108,6 +112,7 @@ namespace skh
         double SigmaY() const override { return 2.0 * Sigmar(); }
         double SigmaZ() const override { return 2.0 * Sigmar(); }
         double Sigmar() const;
+        Vec3 generatePosition(Random& random) const override;  // SpheGeometry.cpp:25-32, SersicGeometry.cpp:41-45
         double reff() const { return _reff; }
         const SersicFunction& function() const { return *_function; }
 
@@ -126,6 +131,7 @@ namespace skh
         double SigmaY() const override { return 2.0 * Sigmar(); }
         double SigmaZ() const override { return 2.0 * Sigmar(); }
         double Sigmar() const;
+        Vec3 generatePosition(Random& random) const override;  // SpheGeometry.cpp:25-32, PlummerGeometry.cpp:29-33
 
     private:
         double _c, _rho0;
@@ -167,6 +173,8 @@ namespace skh
         virtual double massDensity(Vec3 r) const = 0;
         virtual double totalMass() const = 0;
         virtual double totalNumber() const = 0;
+        // Medium::generatePosition (sites of a Voronoi grid with the DustDensity policy)
+        virtual Vec3 generatePosition(Random& random) const = 0;
         // many positions at once (the setup phase samples 100 per tree node and per cell): on the host cores by
         // default; a medium may hand the batch to the GPU
         virtual void massDensities(const std::vector<Vec3>& positions, std::vector<double>& out) const
@@ -207,6 +215,7 @@ namespace skh
         double massDensity(Vec3 r) const override { return mass * geometry->density(r); }
         double totalMass() const override { return mass; }
         double totalNumber() const override { return number; }
+        Vec3 generatePosition(Random& random) const override { return geometry->generatePosition(random); }
         double normalizationWavelength() const override
         {
             return normType == "OpticalDepthMaterialNormalization" ? normWavelength : 0.;
@@ -247,6 +256,10 @@ namespace skh
             double result = snapshot.mass();
             if (!snapshot.holdsNumber()) result /= mix->mass();
             return result;
+        }
+        Vec3 generatePosition(Random&) const override
+        {
+            throw std::runtime_error("random positions from an imported particle medium are not supported on the MI355X path");
         }
         void massDensities(const std::vector<Vec3>& positions, std::vector<double>& out) const override
         {
@@ -338,7 +351,7 @@ namespace skh
         std::string sitesPath;  // resolved file path (policy File)
         VoronoiMesh mesh;
 
-        void setup(Random& random);
+        void setup(Random& random, const Medium& medium);
         int numCells() const override { return mesh.numCells(); }
         Box cellBox(int m) const override { return mesh.cellBox(m); }
         void fill(pmc_grid& g) const override;

@@ -401,7 +401,8 @@ namespace skh
             auto grid = std::make_unique<VoronoiSpatialGrid>();
             grid->extent = extent;
             grid->policy = ge->attr("policy", "DustDensity");
-            if (grid->policy != "Uniform" && grid->policy != "File") unsupported("Voronoi site policy " + grid->policy);
+            if (grid->policy != "Uniform" && grid->policy != "File" && grid->policy != "DustDensity")
+                unsupported("Voronoi site policy " + grid->policy);
             grid->numSites = rd.integer(*ge, "numSites", 500);
             if (grid->policy == "File")
             {
@@ -545,7 +546,7 @@ namespace skh
                 tree->setup(*_medium, _numDensitySamples, _random);
         }
         else if (auto voro = dynamic_cast<VoronoiSpatialGrid*>(_grid.get()))
-            voro->setup(_random);
+            voro->setup(_random, *_medium);
 
         // MediumSystem::setupSelfAfter density sampling (MediumSystem.cpp:80-106,308-321)
         int numCells = _grid->numCells();

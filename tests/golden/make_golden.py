@@ -18,6 +18,7 @@ Fixtures:
                for bit, cell volumes to rounding, sampled densities and output files statistically)
   cfg5_rays*   config 5 at full size (tests/ski/cfg5.ski, 10^5 Voronoi sites from tools/make_sites.py): 208 fixed rays and
                the reference's (m, ds) sequences
+  cfg5dd_cells.npz   the same grid with its sites drawn from the dust density (policy DustDensity): volumes, densities
   cfg4small_*  reduced config 4 (tests/ski/cfg4small.ski): dust imported from 3000 smoothed particles
                (tests/ski/cfg4small_sph.txt, made by tools/make_sph.py), 2x10^4 packets -> files, rays, cells
   *_rays.txt / *_rays_ref.txt   fixed rays and the reference's (m, ds) sequences (C99 hex floats)
@@ -58,7 +59,7 @@ def main():
         sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
     for name, scale in (("cfg1", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg3small", None), ("cfg1nf", None),
                         ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1rf", "rf"), ("cfg3rf", "rf"),
-                        ("cfg5small", 4000 * 3.08567758e16)):
+                        ("cfg5small", 4000 * 3.08567758e16), ("cfg5dd", "cells")):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         ski = os.path.join(ROOT, "tests", "ski", name + ".ski")
@@ -68,6 +69,19 @@ def main():
                 if f.startswith(name) and f.endswith(".txt"):
                     shutil.copy(os.path.join(ROOT, "tests", "ski", f), tmp)
             subprocess.check_call([REF, "run", ski, "-t", "1", "-o", tmp], cwd=tmp, stdout=subprocess.DEVNULL)
+            if scale == "cells":
+                # only the per-cell table (site order through the cell centres, volumes, sampled densities)
+                cells = os.path.join(tmp, "cells.txt")
+                subprocess.check_call([REF, "cells", ski, cells, "-w", "0.55e-6", "-o", tmp], cwd=tmp, stdout=subprocess.DEVNULL)
+                vol, dens = [], []
+                for line in open(cells):
+                    t = line.split()
+                    if t[0] in ("cells", "mix"):
+                        continue
+                    vol.append(float.fromhex(t[4]))
+                    dens.append(float.fromhex(t[5]))
+                np.savez_compressed(os.path.join(HERE, name + "_cells.npz"), volume=np.array(vol), density=np.array(dens))
+                continue
             if scale == "rf":
                 # radiation field variants of scenes above: keep the probe file (gzip) and the SEDs only
                 import gzip

@@ -301,3 +301,16 @@ def test_voronoi_tessellation_is_consistent(tmp_path, kind):
             assert lists[m] <= qhull, (m, lists[m] - qhull)
             # Qhull may list neighbours through faces of vanishing area (co-spherical sites): at most a few
             assert len(qhull - lists[m]) <= 2, (m, qhull - lists[m])
+
+
+def test_voronoi_sites_from_the_dust_density():
+    """VoronoiMeshSpatialGrid policy DustDensity (its default; VoronoiMeshSpatialGrid.cpp:22-40,73-85): the sites are drawn
+    from the medium's geometry with the simulation's random stream (ExpDiskGeometry::generatePosition with Lambert W,
+    one extra deviate per site for the choice of the medium) -- the cells then carry the reference's sampled densities
+    (to 1e-13: the bounding boxes of the cells, from which the sample positions are drawn, agree to rounding)"""
+    sim = Simulation(ski("cfg5dd.ski")).setup()
+    gold = np.load(golden("cfg5dd_cells.npz"))
+    head = scene_head(sim)
+    assert head.grid.kind == 3 and head.grid.num_cells == len(gold["density"]) == 1500
+    dens = np.ctypeslib.as_array(head.medium.number_density, shape=(1500,))
+    assert np.allclose(dens, gold["density"], rtol=1e-12, atol=0)
