@@ -245,9 +245,7 @@ def main():
             # Voronoi: a visit reads the cell's own record (site + density, 32 B) and, for each of its neighbours, the
             # neighbour index (4 B) and the neighbour's site (24 B) -- VoronoiMeshSnapshot.cpp:1096-1150; the mean
             # neighbour count is taken over the cells of the mesh (15.2 for tests/ski/cfg5.ski)
-            import ctypes as C
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from test_host_model import scene_head
+            from skirt9_amd.host import scene_head
             g = scene_head(sim).grid
             nbar = g.vnbr_start[g.num_cells] / g.num_cells
             bytes_per_visit = 32.0 + 28.0 * nbar

@@ -32,6 +32,36 @@ class CounterValues(C.Structure):
 _lib = None
 
 
+# ---- ctypes mirrors of the leading members of pmc_scene (include/pmc.h): inspection of the tables a Simulation hands over
+
+class Grid(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("xmin", C.c_double), ("ymin", C.c_double), ("zmin", C.c_double),
+                ("xmax", C.c_double), ("ymax", C.c_double), ("zmax", C.c_double), ("eps", C.c_double),
+                ("num_cells", C.c_int32), ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("xv", C.POINTER(C.c_double)), ("yv", C.POINTER(C.c_double)), ("zv", C.POINTER(C.c_double)),
+                ("num_nodes", C.c_int32), ("node_box", C.POINTER(C.c_double)), ("node_level", C.POINTER(C.c_int32)),
+                ("node_first_child", C.POINTER(C.c_int32)), ("node_cell", C.POINTER(C.c_int32)),
+                ("nbr_start", C.POINTER(C.c_int32)), ("nbr_list", C.POINTER(C.c_int32)),
+                ("site", C.POINTER(C.c_double)), ("vnbr_start", C.POINTER(C.c_int32)), ("vnbr_list", C.POINTER(C.c_int32)),
+                ("vblock_n", C.c_int32), ("vblock_start", C.POINTER(C.c_int32)), ("vblock_list", C.POINTER(C.c_int32))]
+
+
+class Medium(C.Structure):
+    _fields_ = [("number_density", C.POINTER(C.c_double)), ("num_lambda", C.c_int32),
+                ("lambda_border", C.POINTER(C.c_double)), ("sigma_ext", C.POINTER(C.c_double)),
+                ("sigma_sca", C.POINTER(C.c_double)), ("asymmpar", C.POINTER(C.c_double))]
+
+
+class SceneHead(C.Structure):
+    """leading members of pmc_scene (include/pmc.h)"""
+    _fields_ = [("abi_version", C.c_int32), ("grid", Grid), ("medium", Medium)]
+
+
+def scene_head(sim):
+    """the leading members (grid, medium) of the pmc_scene of a set-up Simulation, for inspection"""
+    return SceneHead.from_address(sim.scene)
+
+
 def lib():
     global _lib
     if _lib is None:
