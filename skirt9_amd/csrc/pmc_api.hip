@@ -135,6 +135,7 @@ namespace
         int tabn{0};
         std::vector<double> table;       // [3][tabn]
         std::vector<LeafRec> leaves;     // by cell index m
+        std::vector<AxisRec> axis;       // [3][numCells]
         std::vector<NodeRec> internals;  // by internal index
         std::vector<int32_t> nbrStart, nbrList;
         uint32_t rootLink{0};
@@ -232,6 +233,7 @@ namespace
 
         const int numCells = g.num_cells;
         T.leaves.assign(numCells, LeafRec{});
+        T.axis.assign(3 * size_t(numCells), AxisRec{});
         T.internals.assign(numInternal, NodeRec{});
         T.nbrStart.assign(6 * size_t(numCells) + 1, 0);
         T.nbrList.clear();
@@ -257,38 +259,15 @@ namespace
             if (id < 0) return fail(PMC_ERR_INVALID, "cell without a leaf node");
             LeafRec& rec = T.leaves[m];
             rec.code = code(id);
-#if PMC_LEAF64
-            for (int a = 0; a < 3; ++a) rec.axis[a].density = density[m];
-#else
             rec.density = density[m];
-#endif
             for (int wall = 0; wall < 6; ++wall)
             {
                 const int axis = wall >> 1, side = wall & 1;
-                const int N = covering(id, wall);
-#if PMC_LEAF64
                 // the leaf across the wall (same size or coarser), or the same-size internal node (finer neighbours: the walk
                 // descends from it by the index bits of its position), or "outside"
-                rec.axis[axis].link[side] = linkOf(N);
-#else
-                const int t1 = axis == 0 ? 1 : 0;  // transverse axes, x before y before z
-                const int t2 = axis == 2 ? 1 : 2;
-                for (int q = 0; q < 4; ++q)
-                {
-                    uint32_t link;
-                    if (N < 0)
-                        link = PMC_LINK_NONE;
-                    else if (g.node_first_child[N] < 0 || g.node_level[N] < g.node_level[id])
-                        link = linkOf(N);  // same-size or coarser leaf (an internal node here cannot be coarser)
-                    else
-                    {
-                        // same-level internal node: its child adjacent to the wall in quadrant q
-                        int l = ((side ? 0 : 1) << axis) | ((q & 1) << t1) | (((q >> 1) & 1) << t2);
-                        link = linkOf(g.node_first_child[N] + l);
-                    }
-                    rec.link[wall][q] = link;
-                }
-#endif
+                AxisRec& hot = T.axis[size_t(axis) * numCells + m];
+                hot.density = density[m];
+                hot.link[side] = linkOf(covering(id, wall));
                 // the reference's neighbour list of this leaf, re-indexed by cell
                 T.nbrStart[6 * size_t(m) + wall] = (int32_t)T.nbrList.size();
                 for (int qq = g.nbr_start[6 * size_t(id) + wall]; qq < g.nbr_start[6 * size_t(id) + wall + 1]; ++qq)
@@ -514,6 +493,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         D.fine_scale[2] = double(1 << T.lmax) / (g.zmax - g.zmin);
         if ((rc = ctx->upload(T.table.data(), T.table.size(), &D.coord_tab))) return bail(rc);
         if ((rc = ctx->upload(T.leaves.data(), T.leaves.size(), &D.leaves))) return bail(rc);
+        if ((rc = ctx->upload(T.axis.data(), T.axis.size(), &D.axis_tab))) return bail(rc);
         if ((rc = ctx->upload(T.internals.data(), T.internals.size(), &D.nodes))) return bail(rc);
         if ((rc = ctx->upload(T.nbrStart.data(), T.nbrStart.size(), &D.nbr_start))) return bail(rc);
         if ((rc = ctx->upload(T.nbrList.data(), T.nbrList.size(), &D.nbr_list))) return bail(rc);

@@ -1,9 +1,8 @@
 // pmc_device.h -- device-side data layout of the MI355X photon-packet engine (shared by host API and kernels).
 //
 // HBM layout (read-only during a segment, replicated per GPU):
-//   octree cells    LeafRec[num_cells]   one 128-byte record (= one L2 line) per cell m: dyadic box code, number
-//                                        density, and FOUR neighbour links per wall (one per quadrant of the wall),
-//                                        so that same-size, coarser and one-level-finer neighbours all cost ONE load
+//   octree cells    AxisRec[3][num_cells] the hot table of the walk step (16 B per cell and exit axis: density + the two links
+//                                        of that axis), LeafRec[num_cells] the cold one (box code, density)
 //   octree nodes    NodeRec[num_internal] 64-byte record per non-leaf node: box code + 8 child links (descent only)
 //   coord table     double[3][2^Lmax+1]  the reference's wall coordinates per axis and dyadic index; staged in LDS
 //   neighbour CSR   int32                the reference's per-wall neighbour lists of every leaf, in the reference's
@@ -30,45 +29,27 @@
 #define PMC_LINK_NODE 0x80000000u
 #define PMC_LINK_MAX_INDEX ((1u << 27) - 2u)
 
-#ifndef PMC_LEAF64
-    #define PMC_LEAF64 1  // 1: 64-byte cell records, ONE 16-byte gather per walk step; 0: 128-byte records, four links per wall
-#endif
-#if PMC_LEAF64
-// One 64-byte record (= one memory sector) per cell.  A walk step leaves the cell through a wall of ONE axis and needs
-// the cell's density and the link through that wall: both come with a single 16-byte gather of axis[a].  A link names
-// the leaf that covers the whole wall (same size or coarser), or the same-size internal node whose children share the
-// wall (finer neighbours): the walk then descends by the index bits of its position, one 4-byte gather per level.
+// Octree cells.  A walk step leaves its cell through a wall of ONE axis and needs the cell's density and the link
+// through that wall: both come with a single 16-byte gather from the HOT table AxisRec[3][num_cells], which is split
+// by exit axis so that four consecutive cells -- siblings, the likely next cells of a walk -- share a 64-byte sector.
+// A link names the leaf that covers the whole wall (same size or coarser), or the same-size internal node whose
+// children share the wall (finer neighbours): the walk then descends by the index bits of its position, one 4-byte
+// gather per level.  LeafRec is the COLD per-cell record (start of a walk, undecided steps).
+struct AxisRec
+{
+    double   density;   // number density n[m] (the same in the three tables)
+    uint32_t link[2];   // through the lower / upper wall of this axis
+};
+static_assert(sizeof(AxisRec) == 16, "AxisRec must be 16 bytes");
+
 struct LeafRec
 {
-    struct
-    {
-        double   density;   // number density n[m] (the same in all three entries)
-        uint32_t link[2];   // through the lower / upper wall of this axis
-    } axis[3];
-    uint64_t code;          // box code: bits 0-19 / 20-39 / 40-59 = byte offsets of the lower x / y / z wall coordinate in the
-                            // LDS table [3][2^Lmax+1], bits 60-63 = size exponent e = Lmax - level
-    uint64_t pad;
+    uint64_t code;      // box code: bits 0-19 / 20-39 / 40-59 = byte offsets of the lower x / y / z wall coordinate in the LDS
+                        // table [3][2^Lmax+1] (8*fx, 8*(tabn+fy), 8*(2 tabn+fz) with fine lower-corner indices f), bits
+                        // 60-63 = size exponent e = Lmax - level (the box spans 2^e finest cells per axis)
+    double   density;   // number density n[m]
 };
-static_assert(sizeof(LeafRec) == 64, "LeafRec must be one 64-byte record");
-#define PMC_LEAF_SHIFT 6
-#define PMC_LEAF_CODE_OFFSET 48
-#define PMC_LEAF_DENSITY(rec) ((rec).axis[0].density)
-#else
-struct LeafRec
-{
-    uint64_t code;        // box code: bits 0-19 / 20-39 / 40-59 = byte offsets of the lower x / y / z wall coordinate in the
-                          // LDS table [3][2^Lmax+1] (i.e. 8*fx, 8*(tabn+fy), 8*(2 tabn+fz) with fine lower-corner indices
-                          // f), bits 60-63 = size exponent e = Lmax - level (the box spans 2^e finest cells per axis)
-    double   density;     // number density n[m]
-    uint32_t link[6][4];  // wall w, quadrant q = (t1 >= c1) + 2 (t2 >= c2) of the two transverse coordinates (x before y
-                          // before z) against the cell centre: the neighbour covering that quadrant at level <= own+1
-    int32_t  pad[4];
-};
-static_assert(sizeof(LeafRec) == 128, "LeafRec must be one 128-byte record");
-#define PMC_LEAF_SHIFT 7
-#define PMC_LEAF_CODE_OFFSET 0
-#define PMC_LEAF_DENSITY(rec) ((rec).density)
-#endif
+static_assert(sizeof(LeafRec) == 16, "LeafRec must be 16 bytes");
 
 struct NodeRec
 {
@@ -169,6 +150,7 @@ struct DevScene
     uint32_t tab_stride_bytes;   // octree: bytes per axis of the coordinate table = 8 * ((1 << lmax) + 1)
     const double* coord_tab;     // [3][(1<<lmax)+1]
     const LeafRec* leaves;
+    const AxisRec* axis_tab;     // [3][num_cells]: the walk step's gather
     const NodeRec* nodes;
     uint32_t root_link;
     const int32_t* nbr_start;    // [6*num_cells + 1]

@@ -36,10 +36,10 @@
 // explicit ones in exactQuotient (pmc_walk.inc), which reproduce IEEE division.
 //
 // Octree traversal (TreeSpatialGrid.cpp:132-217): the reference hops through per-wall neighbour lists of heap
-// nodes.  Here a cell is ONE 128-byte record (LeafRec) holding a box code, the density and four links per wall; wall
-// coordinates come from a per-axis table staged in LDS (exactly the reference's doubles).  A link leads to the
-// neighbour leaf covering that quadrant of the wall (same size, coarser or one level finer) or to an internal node
-// (two or more levels finer), from which the position descends.  This gives the reference's answer whenever the
+// nodes.  Here a walk step issues ONE 16-byte gather from a table split by exit axis (pmc_device.h AxisRec: the cell's
+// density and the links through the two walls of that axis); wall coordinates come from a per-axis table staged in LDS
+// (exactly the reference's doubles).  A link leads to the leaf covering the whole wall (same size or coarser) or to
+// the same-size internal node (finer neighbours), from which the position descends by its index bits.  This gives the reference's answer whenever the
 // new position lies strictly inside the leaf found; in every other case (position on a shared boundary, corner
 // overshoot, rounding, grid boundary) the code falls back to the literal reference algorithm on the neighbour lists
 // kept in HBM in the reference's order, followed by the reference's top-down search and next-after escape.
