@@ -106,16 +106,6 @@ namespace
         return pmc_bits_to_unit(c[0], c[1]);
     }
 
-    // Random::exponCutoff (Random.cpp:105-116)
-    __device__ __forceinline__ double exponCutoff(Rng& rng, uint64_t seed, double xmax)
-    {
-        if (xmax == 0.0) return 0.0;
-        if (xmax < 1e-10) return rngUniform(rng, seed) * xmax;
-        double x = -log(1.0 - rngUniform(rng, seed) * (1.0 - exp(-xmax)));
-        while (x > xmax) x = -log(1.0 - rngUniform(rng, seed) * (1.0 - exp(-xmax)));
-        return x;
-    }
-
     __device__ __forceinline__ void loadRng(const SlotArrays& A, int slot, Rng& rng)
     {
         const uint64_t h = A.history[slot];
