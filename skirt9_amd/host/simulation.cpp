@@ -424,14 +424,21 @@ namespace skh
         {
             InstrumentModel ins;
             ins.type = ie->name;
-            if (ie->name != "FrameInstrument" && ie->name != "FullInstrument") unsupported("instrument " + ie->name);
+            if (ie->name != "FrameInstrument" && ie->name != "FullInstrument" && ie->name != "SEDInstrument")
+                unsupported("instrument " + ie->name);
+            // SEDInstrument (SEDInstrument.cpp:11-22, ApertureInstrument.cpp:11-37): the flux density only; a finite aperture
+            // radius is not supported
+            if (ie->name == "SEDInstrument" && rd.quantity(*ie, "radius", "length", "0") != 0.) unsupported("SEDInstrument with an aperture radius");
             ins.name = ie->attr("instrumentName");
             ins.distance = rd.quantity(*ie, "distance", "distance");
             ins.inclination = rd.quantity(*ie, "inclination", "posangle", "0 deg");
             ins.azimuth = rd.quantity(*ie, "azimuth", "posangle", "0 deg");
             ins.roll = rd.quantity(*ie, "roll", "posangle", "0 deg");
-            ins.fieldOfViewX = rd.quantity(*ie, "fieldOfViewX", "length");
-            ins.fieldOfViewY = rd.quantity(*ie, "fieldOfViewY", "length");
+            if (ie->name != "SEDInstrument")
+            {
+                ins.fieldOfViewX = rd.quantity(*ie, "fieldOfViewX", "length");
+                ins.fieldOfViewY = rd.quantity(*ie, "fieldOfViewY", "length");
+            }
             ins.centerX = rd.quantity(*ie, "centerX", "length", "0");
             ins.centerY = rd.quantity(*ie, "centerY", "length", "0");
             ins.numPixelsX = rd.integer(*ie, "numPixelsX", 250);
@@ -759,8 +766,16 @@ namespace skh
             p.ypmin = ins.centerY - 0.5 * ins.fieldOfViewY;
             p.ypsiz = ins.fieldOfViewY / ins.numPixelsY;
             p.same_observer_as_preceding = ins.sameObserverAsPreceding;
-            p.include_flux_density = ins.type == "FullInstrument";
-            p.include_surface_brightness = 1;
+            p.include_flux_density = ins.type != "FrameInstrument";
+            p.include_surface_brightness = ins.type != "SEDInstrument";
+            if (ins.type == "SEDInstrument")
+            {
+                // no frame: one pixel that covers everything, so that the detection code finds bin 0 (FluxRecorder::detect is
+                // called with l = 0, SEDInstrument.cpp:19-22)
+                p.nxp = p.nyp = 1;
+                p.xpmin = p.ypmin = -0.25 * DBL_MAX;
+                p.xpsiz = p.ypsiz = 0.5 * DBL_MAX;
+            }
             p.record_components = ins.recordComponents;  // a medium is always present on this path
             p.num_scattering_levels = ins.recordComponents ? ins.numScatteringLevels : 0;
             p.record_statistics = ins.recordStatistics;

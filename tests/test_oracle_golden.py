@@ -22,7 +22,7 @@ def _same_file(path_a, path_b):
     return a == b
 
 
-@pytest.mark.parametrize("name,nfiles", [("cfg1", 11), ("cfg2small", 11), ("cfg3small", 27), ("cfg1nf", 12), ("cfg4small", 11), ("cfg1file", 11)])
+@pytest.mark.parametrize("name,nfiles", [("cfg1", 11), ("cfg2small", 11), ("cfg3small", 27), ("cfg1nf", 12), ("cfg4small", 11), ("cfg1file", 11), ("cfg1sed", 14)])
 def test_byte_identical_to_reference(name, nfiles, tmp_path):
     """cfg3small: panchromatic sampling with a wavelength bias, tabulated dust, 20 wavelength bins, and three
     instruments (scattering levels, a FrameInstrument sharing its observer, a second observer); cfg1nf: non-forced
@@ -31,7 +31,8 @@ def test_byte_identical_to_reference(name, nfiles, tmp_path):
     frames, counters = O.run_primary(sim, 0, sim.num_packets, O.RNG_MT19937)
     assert counters.histories == sim.num_packets
     sim.write(frames, str(tmp_path))
-    expected = sorted(f for f in os.listdir(golden("")) if f.startswith(name + "_i") and (f.endswith(".fits") or f.endswith(".dat")))
+    expected = sorted(f for f in os.listdir(golden("")) if (f.startswith(name + "_i") or f.startswith(name + "_s"))
+                      and (f.endswith(".fits") or f.endswith(".dat")))
     assert len(expected) == nfiles
     for f in expected:
         assert os.path.exists(tmp_path / f), f
