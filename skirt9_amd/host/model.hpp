@@ -372,8 +372,11 @@ namespace skh
         double wavelengthBias{0.5};
         std::string biasDistType{"DefaultWavelengthDistribution"};
         double biasMin{0}, biasMax{0};
-        // BlackBodySED
+        // BlackBodySED, or a tabulated SED (ListSED / FileSED: wavelengths and specific luminosities per unit of wavelength,
+        // arbitrarily scaled; TabulatedSED.cpp:12-25)
+        std::string sedType{"BlackBodySED"};
         double temperature{5000.};
+        Array sedInLambda, sedInP;
         // IntegratedLuminosityNormalization
         std::string normRange{"Source"};
         double normMinWavelength{0.09e-6}, normMaxWavelength{100e-6}, integratedLuminosity{0};

@@ -274,7 +274,17 @@ namespace skh
                 if (c + 1 > fileCols.size()) throw std::runtime_error("No column info in file header for column " + std::to_string(c + 1));
                 unit = fileCols[c].unit;
             }
-            if (columns[c].quantity.empty())
+            if (columns[c].quantity == "specific")
+            {
+                // an arbitrarily scaled value per unit of wavelength (TextInFile.cpp:232-245): the unit must be one of the
+                // per-wavelength styles, and NO conversion factor is applied (waveExponent 0); the per-frequency, neutral
+                // and per-energy styles would need the wavelength column and are not supported here
+                if (!unitTable().has("wavelengthmonluminosity", unit))
+                    throw std::runtime_error("Invalid or unsupported units (" + unit + ") for specific quantity in column "
+                                             + std::to_string(c + 1) + " (only per-wavelength units are supported)");
+                conv[c] = UnitFactor{1., 1., 0.};
+            }
+            else if (columns[c].quantity.empty())
             {
                 if (!unit.empty() && unit != "1")
                     throw std::runtime_error("Invalid units (" + unit + ") for dimensionless quantity in column " + std::to_string(c + 1));

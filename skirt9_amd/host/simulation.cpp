@@ -218,8 +218,44 @@ namespace skh
             unsupported("source " + src.name);
         if (const XmlElement* sed = src.item("sed"))
         {
-            if (sed->name != "BlackBodySED") unsupported("SED " + sed->name);
-            _source.temperature = rd.quantity(*sed, "temperature", "temperature", "5000 K");
+            _source.sedType = sed->name;
+            if (sed->name == "BlackBodySED")
+                _source.temperature = rd.quantity(*sed, "temperature", "temperature", "5000 K");
+            else if (sed->name == "ListSED")
+            {
+                // ListSED.cpp:11-18 with the default unit style (per unit of wavelength)
+                if (sed->attr("unitStyle", "wavelengthmonluminosity") != "wavelengthmonluminosity")
+                    unsupported("ListSED unitStyle " + sed->attr("unitStyle", ""));
+                _source.sedInLambda = rd.list(*sed, "wavelengths", "wavelength", "");
+                _source.sedInP = rd.list(*sed, "specificLuminosities", "wavelengthmonluminosity", "");
+                if (_source.sedInLambda.size() != _source.sedInP.size())
+                    throw std::runtime_error("Number of listed luminosities does not match number of listed wavelengths");
+            }
+            else if (sed->name == "FileSED")
+            {
+                // FileSED.cpp:11-18
+                std::string filename = sed->attr("filename", "");
+                if (filename.empty()) throw std::runtime_error("ski: FileSED lacks a filename");
+                std::string path = (filename[0] == '/') ? filename : _inputPath + "/" + filename;
+                for (const Array& row : readColumnFile(path, {{"wavelength", "wavelength", "micron"}, {"specific luminosity", "specific", "W/m"}},
+                                                       "spectral energy distribution"))
+                {
+                    _source.sedInLambda.push_back(row[0]);
+                    _source.sedInP.push_back(row[1]);
+                }
+            }
+            else
+                unsupported("SED " + sed->name);
+            if (sed->name != "BlackBodySED")
+            {
+                // TabulatedSED::setupSelfBefore (TabulatedSED.cpp:14-21)
+                if (_source.sedInLambda.size() < 2) throw std::runtime_error("SED must have at least two wavelength/luminosity pairs");
+                if (_source.sedInLambda.front() > _source.sedInLambda.back())
+                {
+                    std::reverse(_source.sedInLambda.begin(), _source.sedInLambda.end());
+                    std::reverse(_source.sedInP.begin(), _source.sedInP.end());
+                }
+            }
         }
         if (const XmlElement* norm = src.item("normalization"))
         {
@@ -593,7 +629,28 @@ namespace skh
         double f1 = h * c / (k * _source.temperature);
         double f2 = 2.0 * h * c * c;
         auto planck = [&](double lambda) { return f2 / pow(lambda, 5) / (exp(f1 / lambda) - 1.0); };
+        const bool tabulated = _source.sedType != "BlackBodySED";
+        // NR::cdf<NR::interpolateLogLog>(xv, pv, Pv, inxv, inpv, range) (NR.hpp:494-520): the tabulated function restricted to
+        // a range, its end points interpolated, and the normalised cumulative distribution
+        auto tableCdf = [&](Array& xv, Array& pv, Array& Pv, const Array& inxv, const Array& inpv, double lo, double hi) {
+            size_t minRight = std::upper_bound(inxv.begin(), inxv.end(), lo) - inxv.begin();
+            size_t maxRight = std::lower_bound(inxv.begin(), inxv.end(), hi) - inxv.begin();
+            size_t n = 1 + maxRight - minRight;
+            xv.assign(n + 1, 0.);
+            size_t i = 0;
+            xv[i++] = lo;
+            for (size_t j = minRight; j < maxRight;) xv[i++] = inxv[j++];
+            xv[i++] = hi;
+            pv.assign(n + 1, 0.);
+            pv[0] = minRight == 0 ? 0. : nr::interpolateLogLog(xv[0], inxv[minRight - 1], inxv[minRight], inpv[minRight - 1], inpv[minRight]);
+            for (size_t q = 1; q < n; ++q) pv[q] = inpv[minRight + q - 1];
+            pv[n] = maxRight == inxv.size()
+                        ? 0.
+                        : nr::interpolateLogLog(xv[n], inxv[maxRight - 1], inxv[maxRight], inpv[maxRight - 1], inpv[maxRight]);
+            return nr::cdf2(true, xv, pv, Pv);
+        };
         auto planckCdf = [&](Array& lambdav, Array& pv, Array& Pv, double lo, double hi) {
+            if (tabulated) return tableCdf(lambdav, pv, Pv, _source.sedInLambda, _source.sedInP, lo, hi);
             size_t n = std::max(static_cast<size_t>(100), static_cast<size_t>(1000. * log10(hi / lo)));
             nr::logGrid(lambdav, lo, hi, static_cast<int>(n));
             pv.resize(n + 1);
@@ -601,7 +658,15 @@ namespace skh
             return nr::cdf2(true, lambdav, pv, Pv);
         };
         double Ltot = planckCdf(_sedLambda, _sedp, _sedP, sourceMin, sourceMax);
-        auto specificLuminosity = [&](double lambda) { return planck(lambda) / Ltot; };
+        if (tabulated)
+            for (double& v : _source.sedInP) v /= Ltot;  // TabulatedSED.cpp:20-21 (the later integrals use the normalised table)
+        auto specificLuminosity = [&](double lambda) {
+            if (!tabulated) return planck(lambda) / Ltot;
+            // NR::value<NR::interpolateLogLog> (NR.hpp:372-378)
+            int i = nr::locateFail(_source.sedInLambda, lambda);
+            if (i < 0 || lambda < _source.sedInLambda.front()) return 0.;
+            return nr::interpolateLogLog(lambda, _source.sedInLambda[i], _source.sedInLambda[i + 1], _source.sedInP[i], _source.sedInP[i + 1]);
+        };
 
         // IntegratedLuminosityNormalization::luminosityForSED (IntegratedLuminosityNormalization.cpp:12-31)
         if (_source.normRange == "Source")
@@ -612,7 +677,7 @@ namespace skh
             double hi = _source.normRange == "Custom" ? _source.normMaxWavelength : 1;
             if (lo >= hi) throw std::runtime_error("the normalization wavelength range is empty");
             Array a, b, cc;
-            double L = planckCdf(a, b, cc, lo, hi) / Ltot;
+            double L = planckCdf(a, b, cc, lo, hi) / (tabulated ? 1. : Ltot);
             if (L <= 0) throw std::runtime_error("the normalization luminosity is zero");
             _sourceLuminosity = _source.integratedLuminosity / L;
         }
@@ -662,7 +727,7 @@ namespace skh
             _scene.source.sed_lambda = _sedLambda.data();
             _scene.source.sed_p = _sedp.data();
             _scene.source.sed_P = _sedP.data();
-            _scene.source.sed_kind = PMC_SED_BLACKBODY;
+            _scene.source.sed_kind = tabulated ? PMC_SED_TABULATED : PMC_SED_BLACKBODY;
             _scene.source.sed_f1 = f1;
             _scene.source.sed_f2 = f2;
             _scene.source.sed_ltot = Ltot;

@@ -103,6 +103,14 @@ namespace skh
             add("wavelengthsurfacebrightness", "W/m2/micron/sr", 1e6);
             add("wavelengthsurfacebrightness", "W/m2/micron/arcsec2", 1e6 / arcsec2);
             add("neutralfluxdensity", "W/m2", 1.);
+            // specific luminosity per unit of wavelength (a tabulated SED; only the wavelength style is supported on this path)
+            add("wavelengthmonluminosity", "W/m", 1.);
+            add("wavelengthmonluminosity", "W/micron", 1e6);
+            add("wavelengthmonluminosity", "W/Angstrom", 1e10);
+            add("wavelengthmonluminosity", "erg/s/cm", 1e-5);
+            add("wavelengthmonluminosity", "erg/s/micron", 1e-1);
+            add("wavelengthmonluminosity", "erg/s/Angstrom", 1e3);
+            add("wavelengthmonluminosity", "Lsun/micron", constants::Lsun * 1e6);
             add("neutralmeanintensity", "W/m2/sr", 1.);
             add("wavelengthmeanintensity", "W/m3/sr", 1.);
             add("wavelengthmeanintensity", "W/m2/micron/sr", 1e6);

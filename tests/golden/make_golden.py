@@ -11,6 +11,7 @@ Fixtures:
   cfg3small_*  reduced config 3 (tests/ski/cfg3small.ski): panchromatic, four instruments, 2x10^4 packets -> files
   cfg1nf_*     non-forced scattering variant of config 1 (tests/ski/cfg1nf.ski): 2x10^5 packets -> files
   cfg1sed_*    config 1 with two SEDInstruments next to the FullInstrument (tests/ski/cfg1sed.ski): 10^5 packets -> files
+  cfg3sed_*    reduced config 3 with a FileSED source spectrum (tests/ski/cfg3sed.ski + cfg3sed_sed.txt) -> files
   cfg1file_*   config 1 with MeanFileDustMix (tests/ski/cfg1file.ski + cfg1file_dust.txt): 10^5 packets -> files
   cfg1rf_*, cfg3rf_*   config 1 and reduced config 3 with storeRadiationField and a RadiationFieldProbe (PerCellForm):
                the probe file <name>_rf_J.dat (gzip) and the SED files
@@ -59,7 +60,7 @@ def main():
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
     for name, scale in (("cfg1", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg3small", None), ("cfg1nf", None),
-                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1sed", None), ("cfg1rf", "rf"), ("cfg3rf", "rf"),
+                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1sed", None), ("cfg3sed", None), ("cfg1rf", "rf"), ("cfg3rf", "rf"),
                         ("cfg5small", 4000 * 3.08567758e16), ("cfg5dd", "cells")):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue

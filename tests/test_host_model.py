@@ -290,3 +290,57 @@ def test_voronoi_sites_from_the_dust_density():
     assert head.grid.kind == 3 and head.grid.num_cells == len(gold["density"]) == 1500
     dens = np.ctypeslib.as_array(head.medium.number_density, shape=(1500,))
     assert np.allclose(dens, gold["density"], rtol=1e-12, atol=0)
+
+
+# ---------------------------------------------------------------- tabulated source spectra
+
+class SourceHead(C.Structure):
+    """pmc_options + the leading members of pmc_source that follow pmc_medium in pmc_scene (include/pmc.h)"""
+    _fields_ = [("force_scattering", C.c_int32), ("min_weight_reduction", C.c_double), ("min_scatt_events", C.c_int32),
+                ("path_length_bias", C.c_double),
+                ("kind", C.c_int32), ("position", C.c_double * 3), ("reff", C.c_double), ("sersic_n", C.c_int32),
+                ("sersic_s", C.POINTER(C.c_double)), ("sersic_M", C.POINTER(C.c_double)), ("box", C.c_double * 6),
+                ("packet_luminosity", C.c_double), ("lambda_mode", C.c_int32), ("num_oligo", C.c_int32),
+                ("oligo_lambda", C.POINTER(C.c_double)), ("oligo_weight", C.POINTER(C.c_double)), ("lambda_bias", C.c_double),
+                ("num_sed", C.c_int32), ("sed_lambda", C.POINTER(C.c_double)), ("sed_p", C.POINTER(C.c_double)),
+                ("sed_P", C.POINTER(C.c_double))]
+
+
+class SceneWithSource(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("grid", Grid), ("medium", Medium), ("src", SourceHead)]
+
+
+def _sed_tables(sim):
+    src = SceneWithSource.from_address(sim.scene).src
+    n = src.num_sed
+    return (np.ctypeslib.as_array(src.sed_lambda, shape=(n,)).copy(), np.ctypeslib.as_array(src.sed_p, shape=(n,)).copy(),
+            np.ctypeslib.as_array(src.sed_P, shape=(n,)).copy())
+
+
+def test_list_sed_equals_file_sed(tmp_path):
+    """ListSED (ListSED.cpp:11-18) and FileSED (FileSED.cpp:11-18) with the same numbers give the same sampling tables
+    (TabulatedSED.cpp:14-21: table cut to the source range with interpolated end points, log-log cumulative
+    distribution); the table is normalised to 1 and ends at 1"""
+    sim_file = Simulation(ski("cfg3sed.ski")).setup()
+    text = open(ski("cfg3sed.ski")).read().replace(
+        '<FileSED filename="cfg3sed_sed.txt"/>',
+        '<ListSED unitStyle="wavelengthmonluminosity" wavelengths="0.09 micron, 0.15 micron, 0.3 micron, 0.55 micron, 1 micron, '
+        '2.2 micron, 5 micron, 20 micron" specificLuminosities="0.1 W/micron, 1.5 W/micron, 9 W/micron, 19 W/micron, '
+        '14 W/micron, 6 W/micron, 0.9 W/micron, 0.02 W/micron"/>')
+    (tmp_path / "l.ski").write_text(text)
+    sim_list = Simulation(str(tmp_path / "l.ski")).setup()
+    a, b = _sed_tables(sim_file), _sed_tables(sim_list)
+    assert len(a[0]) == len(b[0]) == 8      # 0.1 | 0.15 0.3 0.55 1 2.2 5 | 10 micron
+    assert np.isclose(a[0][0], 0.1e-6, rtol=1e-14) and np.isclose(a[0][-1], 10e-6, rtol=1e-14)
+    for x, y in zip(a, b):
+        # (the list carries W/micron values, the file's specific column is not scaled: the normalised tables agree)
+        assert np.allclose(x, y, rtol=1e-13, atol=0)
+    assert a[2][0] == 0.0 and a[2][-1] == 1.0 and np.all(np.diff(a[2]) > 0)
+
+
+def test_file_sed_rejects_frequency_style_units(tmp_path):
+    text = open(ski("cfg3sed.ski")).read().replace('filename="cfg3sed_sed.txt"', 'filename="s.txt"')
+    (tmp_path / "s.txt").write_text("# Column 1: wavelength (micron)\n# Column 2: specific luminosity (W/Hz)\n0.1 1\n10 1\n")
+    (tmp_path / "s.ski").write_text(text)
+    with pytest.raises(Exception, match="only per-wavelength units"):
+        Simulation(str(tmp_path / "s.ski")).setup()
