@@ -377,7 +377,10 @@ namespace skh
         std::string sedType{"BlackBodySED"};
         double temperature{5000.};
         Array sedInLambda, sedInP;
-        // IntegratedLuminosityNormalization
+        // IntegratedLuminosityNormalization, or SpecificLuminosityNormalization (normType; specific luminosity per unit of
+        // wavelength at normWavelength after Units::fromFluxStyle)
+        std::string normType{"IntegratedLuminosityNormalization"};
+        double normWavelength{0}, specificLuminosity{0};
         std::string normRange{"Source"};
         double normMinWavelength{0.09e-6}, normMaxWavelength{100e-6}, integratedLuminosity{0};
     };

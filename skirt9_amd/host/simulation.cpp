@@ -259,11 +259,27 @@ namespace skh
         }
         if (const XmlElement* norm = src.item("normalization"))
         {
-            if (norm->name != "IntegratedLuminosityNormalization") unsupported("luminosity normalization " + norm->name);
+            _source.normType = norm->name;
+            if (norm->name == "SpecificLuminosityNormalization")
+            {
+                // SpecificLuminosityNormalization.cpp:12-21 with Units::fromFluxStyle (Units.cpp:41-51)
+                std::string style = norm->attr("unitStyle", "wavelengthmonluminosity");
+                if (style != "wavelengthmonluminosity" && style != "neutralmonluminosity" && style != "frequencymonluminosity")
+                    unsupported("SpecificLuminosityNormalization unitStyle " + style);
+                _source.normWavelength = rd.quantity(*norm, "wavelength", "wavelength");
+                double L = rd.quantity(*norm, "specificLuminosity", style.c_str());
+                const double lambda = _source.normWavelength;
+                if (style == "neutralmonluminosity") L = L / lambda;
+                if (style == "frequencymonluminosity") L = L * constants::c / lambda / lambda;
+                _source.specificLuminosity = L;
+            }
+            else if (norm->name != "IntegratedLuminosityNormalization")
+                unsupported("luminosity normalization " + norm->name);
             _source.normRange = norm->attr("wavelengthRange", "Source");
             _source.normMinWavelength = rd.quantity(*norm, "minWavelength", "wavelength", "0.09 micron");
             _source.normMaxWavelength = rd.quantity(*norm, "maxWavelength", "wavelength", "100 micron");
-            _source.integratedLuminosity = rd.quantity(*norm, "integratedLuminosity", "bolluminosity");
+            if (norm->name == "IntegratedLuminosityNormalization")
+                _source.integratedLuminosity = rd.quantity(*norm, "integratedLuminosity", "bolluminosity");
         }
         else
             throw std::runtime_error("ski: source lacks a luminosity normalization");
@@ -669,7 +685,13 @@ namespace skh
         };
 
         // IntegratedLuminosityNormalization::luminosityForSED (IntegratedLuminosityNormalization.cpp:12-31)
-        if (_source.normRange == "Source")
+        if (_source.normType == "SpecificLuminosityNormalization")
+        {
+            double LlambdaSED = specificLuminosity(_source.normWavelength);
+            if (LlambdaSED <= 0) throw std::runtime_error("The normalization wavelength is outside of the SED's wavelength range");
+            _sourceLuminosity = _source.specificLuminosity / LlambdaSED;
+        }
+        else if (_source.normRange == "Source")
             _sourceLuminosity = _source.integratedLuminosity;
         else
         {

@@ -111,6 +111,12 @@ namespace skh
             add("wavelengthmonluminosity", "erg/s/micron", 1e-1);
             add("wavelengthmonluminosity", "erg/s/Angstrom", 1e3);
             add("wavelengthmonluminosity", "Lsun/micron", constants::Lsun * 1e6);
+            add("neutralmonluminosity", "W", 1.);
+            add("neutralmonluminosity", "erg/s", 1e-7);
+            add("neutralmonluminosity", "Lsun", constants::Lsun);
+            add("frequencymonluminosity", "W/Hz", 1.);
+            add("frequencymonluminosity", "erg/s/Hz", 1e-7);
+            add("frequencymonluminosity", "Lsun/Hz", constants::Lsun);
             add("neutralmeanintensity", "W/m2/sr", 1.);
             add("wavelengthmeanintensity", "W/m3/sr", 1.);
             add("wavelengthmeanintensity", "W/m2/micron/sr", 1e6);

@@ -12,6 +12,7 @@ Fixtures:
   cfg1nf_*     non-forced scattering variant of config 1 (tests/ski/cfg1nf.ski): 2x10^5 packets -> files
   cfg1sed_*    config 1 with two SEDInstruments next to the FullInstrument (tests/ski/cfg1sed.ski): 10^5 packets -> files
   cfg3sed_*    reduced config 3 with a FileSED source spectrum (tests/ski/cfg3sed.ski + cfg3sed_sed.txt) -> files
+  cfg3norm_*   the same with a SpecificLuminosityNormalization (per unit of frequency): SED files only
   cfg1file_*   config 1 with MeanFileDustMix (tests/ski/cfg1file.ski + cfg1file_dust.txt): 10^5 packets -> files
   cfg1rf_*, cfg3rf_*   config 1 and reduced config 3 with storeRadiationField and a RadiationFieldProbe (PerCellForm):
                the probe file <name>_rf_J.dat (gzip) and the SED files
@@ -60,7 +61,7 @@ def main():
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
     for name, scale in (("cfg1", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg3small", None), ("cfg1nf", None),
-                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1sed", None), ("cfg3sed", None), ("cfg1rf", "rf"), ("cfg3rf", "rf"),
+                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1sed", None), ("cfg3sed", None), ("cfg3norm", "sed"), ("cfg1rf", "rf"), ("cfg3rf", "rf"),
                         ("cfg5small", 4000 * 3.08567758e16), ("cfg5dd", "cells")):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
@@ -68,7 +69,7 @@ def main():
         with tempfile.TemporaryDirectory() as tmp:
             # input files named in the ski file are read from the working directory (FilePaths::input)
             for f in os.listdir(os.path.join(ROOT, "tests", "ski")):
-                if f.startswith(name) and f.endswith(".txt"):
+                if f.endswith(".txt"):
                     shutil.copy(os.path.join(ROOT, "tests", "ski", f), tmp)
             subprocess.check_call([REF, "run", ski, "-t", "1", "-o", tmp], cwd=tmp, stdout=subprocess.DEVNULL)
             if scale == "cells":
@@ -83,6 +84,11 @@ def main():
                     vol.append(float.fromhex(t[4]))
                     dens.append(float.fromhex(t[5]))
                 np.savez_compressed(os.path.join(HERE, name + "_cells.npz"), volume=np.array(vol), density=np.array(dens))
+                continue
+            if scale == "sed":
+                for f in sorted(os.listdir(tmp)):
+                    if f.endswith("_sed.dat"):
+                        shutil.copy(os.path.join(tmp, f), os.path.join(HERE, f))
                 continue
             if scale == "rf":
                 # radiation field variants of scenes above: keep the probe file (gzip) and the SEDs only

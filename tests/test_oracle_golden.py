@@ -207,3 +207,15 @@ def test_full_size_voronoi_rays_bit_exact(tmp_path):
         assert np.array_equal(ds.view(np.uint64), ds_ref.view(np.uint64))
         total += len(m_ref)
     assert total > 7000
+
+
+def test_specific_luminosity_normalization(tmp_path):
+    """SpecificLuminosityNormalization (SpecificLuminosityNormalization.cpp:12-21) with a per-frequency value
+    (Units::fromFluxStyle): the SED files equal the reference's byte for byte"""
+    sim = Simulation(ski("cfg3norm.ski")).setup()
+    frames, _ = O.run_primary(sim, 0, sim.num_packets, O.RNG_MT19937)
+    sim.write(frames, str(tmp_path))
+    expected = [f for f in os.listdir(golden("")) if f.startswith("cfg3norm_") and f.endswith("_sed.dat")]
+    assert len(expected) == 2
+    for f in expected:
+        assert _same_file(golden(f), str(tmp_path / f)), f
