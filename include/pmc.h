@@ -121,7 +121,7 @@ typedef struct pmc_options
 
 /* ---------------------------------------------------------------- source ---- */
 
-enum { PMC_SOURCE_POINT = 1, PMC_SOURCE_SERSIC = 2, PMC_SOURCE_UNIFORM_BOX = 3 };
+enum { PMC_SOURCE_POINT = 1, PMC_SOURCE_SERSIC = 2, PMC_SOURCE_UNIFORM_BOX = 3, PMC_SOURCE_EXP_DISK = 4, PMC_SOURCE_PLUMMER = 5 };
 enum { PMC_LAMBDA_OLIGO = 1, PMC_LAMBDA_TABULATED = 2 };
 enum { PMC_BIAS_NONE = 0, PMC_BIAS_LOG = 1, PMC_BIAS_LIN = 2 };
 enum { PMC_SED_TABULATED = 0, PMC_SED_BLACKBODY = 1 };
@@ -134,7 +134,10 @@ typedef struct pmc_source
     int32_t sersic_n;               /*   number of table points (101) */
     const double* sersic_s;         /*   _sv */
     const double* sersic_M;         /*   _Mv (cumulative mass, normalised) */
-    double  box[6];                 /* uniform box source: xmin,ymin,zmin,xmax,ymax,zmax */
+    double  box[6];                 /* uniform box source: xmin,ymin,zmin,xmax,ymax,zmax;
+                                       exponential disk (ExpDiskGeometry.cpp:46-68, SepAxGeometry.cpp:11-19): scale length,
+                                       scale height, min radius, max radius (0: none), max |z| (0: none);
+                                       Plummer sphere (PlummerGeometry.cpp:29-33): scale length */
 
     double  packet_luminosity;      /* L/Npp * Lv[h]/Wv[h]  (SourceSystem.cpp:96,105-106), before the lambda weight */
 

@@ -118,6 +118,52 @@ namespace
         double x, y, z;
     };
 
+    // SpecialFunctions::LambertW1 (SKIRT/utils/SpecialFunctions.cpp:578-625)
+    double lambertW1(double z)
+    {
+        const double eps = 1.0e-12;
+        const double em1 = 0.3678794411714423215955237701614608;
+        const double c[12] = {-1.0,
+                                     2.331643981597124203363536062168,
+                                     -1.812187885639363490240191647568,
+                                     1.936631114492359755363277457668,
+                                     -2.353551201881614516821543561516,
+                                     3.066858901050631912893148922704,
+                                     -4.175335600258177138854984177460,
+                                     5.858023729874774148815053846119,
+                                     -8.401032217523977370984161688514,
+                                     12.250753501314460424,
+                                     -18.100697012472442755,
+                                     27.029044799010561650};
+        if (z == 0.0) return -DBL_MAX;
+        double q = z + em1;
+        double r = -sqrt(q);
+        double t8 = c[8] + r * (c[9] + r * (c[10] + r * c[11]));
+        double t5 = c[5] + r * (c[6] + r * (c[7] + r * t8));
+        double t1 = c[1] + r * (c[2] + r * (c[3] + r * (c[4] + r * t5)));
+        double w0 = c[0] + r * t1;
+        if (q < 3.0e-3) return w0;
+        double w;
+        if (z < -1e-6)
+            w = w0;
+        else
+        {
+            double l1 = log(-z);
+            double l2 = log(-l1);
+            w = l1 - l2 + l2 / l1;
+        }
+        for (int i = 0; i < 10; i++)
+        {
+            double e = exp(w);
+            double t = w * e - z;
+            double p = w + 1.0;
+            t /= e * p - 0.5 * (p + 1.0) * t / p;
+            w -= t;
+            if (fabs(t) < eps * (1.0 + fabs(w))) return w;
+        }
+        return w;  // (the reference raises "No convergence": unreachable for arguments in [-1/e, 0])
+    }
+
     // Direction(theta, phi) (Direction.cpp:11-38)
     V3 directionFromAngles(double theta, double phi)
     {
@@ -706,6 +752,34 @@ namespace
                 double radius = s.reff * sv;
                 V3 d = randomDirection(rng);
                 r = V3{d.x * radius, d.y * radius, d.z * radius};
+            }
+            else if (s.kind == PMC_SOURCE_EXP_DISK)
+            {
+                // ExpDiskGeometry::randomCylRadius / randomZ with SepAxGeometry::generatePosition
+                // (ExpDiskGeometry.cpp:46-68, SepAxGeometry.cpp:11-19)
+                const double hR = s.box[0], hz = s.box[1], Rmin = s.box[2], Rmax = s.box[3], zmax = s.box[4];
+                double R, X;
+                do
+                {
+                    X = rng.uniform();
+                    R = hR * (-1.0 - lambertW1((X - 1.0) / M_E));
+                } while ((Rmax > 0.0 && R >= Rmax) || R <= Rmin);
+                double phi = 2.0 * M_PI * rng.uniform();
+                double z;
+                do
+                {
+                    X = rng.uniform();
+                    z = (X <= 0.5) ? hz * log(2.0 * X) : -hz * log(2.0 * (1.0 - X));
+                } while (zmax > 0.0 && fabs(z) >= zmax);
+                r = V3{R * cos(phi), R * sin(phi), z};
+            }
+            else if (s.kind == PMC_SOURCE_PLUMMER)
+            {
+                // PlummerGeometry::randomRadius + SpheGeometry::generatePosition (PlummerGeometry.cpp:29-33)
+                double t = pow(rng.uniform(), 1.0 / 3.0);
+                double radius = s.box[0] * t / sqrt((1.0 - t) * (1.0 + t));
+                V3 d = randomDirection(rng);
+                r = V3{radius * d.x, radius * d.y, radius * d.z};
             }
             else
             {

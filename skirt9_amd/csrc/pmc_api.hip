@@ -545,7 +545,8 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if ((rc = ctx->upload(src.sersic_M, src.sersic_n, &D.sersic_M))) return bail(rc);
         transDoubles += 2 * src.sersic_n;
     }
-    else if (src.kind != PMC_SOURCE_POINT && src.kind != PMC_SOURCE_UNIFORM_BOX)
+    else if (src.kind != PMC_SOURCE_POINT && src.kind != PMC_SOURCE_UNIFORM_BOX && src.kind != PMC_SOURCE_EXP_DISK
+             && src.kind != PMC_SOURCE_PLUMMER)
         return bail(fail(PMC_ERR_UNSUPPORTED, "unsupported source kind"));
     if (src.lambda_mode == PMC_LAMBDA_OLIGO)
     {

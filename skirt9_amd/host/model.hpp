@@ -97,6 +97,7 @@ namespace skh
         double SigmaZ() const override;
         double SigmaR() const;
         Vec3 generatePosition(Random& random) const override;  // SepAxGeometry.cpp:11-19, ExpDiskGeometry.cpp:46-68
+        void parameters(double v[5]) const { v[0] = _hR, v[1] = _hz, v[2] = _Rmin, v[3] = _Rmax, v[4] = _zmax; }
 
     private:
         double _hR, _hz, _Rmin, _Rmax, _zmax, _rho0;
@@ -132,6 +133,7 @@ namespace skh
         double SigmaZ() const override { return 2.0 * Sigmar(); }
         double Sigmar() const;
         Vec3 generatePosition(Random& random) const override;  // SpheGeometry.cpp:25-32, PlummerGeometry.cpp:29-33
+        double scaleLength() const { return _c; }
 
     private:
         double _c, _rho0;

@@ -209,7 +209,8 @@ namespace skh
         {
             const XmlElement* g = src.item("geometry");
             if (!g) throw std::runtime_error("ski: GeometricSource lacks a geometry");
-            if (g->name != "SersicGeometry" && g->name != "UniformBoxGeometry") unsupported("source geometry " + g->name);
+            if (g->name != "SersicGeometry" && g->name != "UniformBoxGeometry" && g->name != "ExpDiskGeometry" && g->name != "PlummerGeometry")
+                unsupported("source geometry " + g->name);
             _source.geometry = makeGeometry(*g, rd);
             if (src.item("velocityDistribution") && rd.quantity(src, "velocityMagnitude", "velocity", "0") && !_oligo)
                 unsupported("a source with a velocity field");
@@ -817,6 +818,16 @@ namespace skh
             const Box& b = ubox->box();
             double v[6] = {b.xmin, b.ymin, b.zmin, b.xmax, b.ymax, b.zmax};
             std::memcpy(s.box, v, sizeof(v));
+        }
+        else if (auto disk = dynamic_cast<ExpDiskGeometry*>(_source.geometry.get()))
+        {
+            s.kind = PMC_SOURCE_EXP_DISK;
+            disk->parameters(s.box);
+        }
+        else if (auto plummer = dynamic_cast<PlummerGeometry*>(_source.geometry.get()))
+        {
+            s.kind = PMC_SOURCE_PLUMMER;
+            s.box[0] = plummer->scaleLength();
         }
 
         // instruments (DistantInstrument.cpp:13-51, FrameInstrument.cpp:12-33, FullInstrument.cpp:11-17)

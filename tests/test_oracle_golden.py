@@ -219,3 +219,17 @@ def test_specific_luminosity_normalization(tmp_path):
     assert len(expected) == 2
     for f in expected:
         assert _same_file(golden(f), str(tmp_path / f)), f
+
+
+@pytest.mark.parametrize("name", ["cfg3disk", "cfg3plum"])
+def test_disk_and_plummer_sources(tmp_path, name):
+    """launch positions drawn from a truncated exponential disk (ExpDiskGeometry.cpp:46-68: Lambert W_-1 for the radius,
+    rejection on the truncations) and from a Plummer sphere (PlummerGeometry.cpp:29-33): the SED files equal the
+    reference's byte for byte"""
+    sim = Simulation(ski(name + ".ski")).setup()
+    frames, _ = O.run_primary(sim, 0, sim.num_packets, O.RNG_MT19937)
+    sim.write(frames, str(tmp_path))
+    expected = [f for f in os.listdir(golden("")) if f.startswith(name + "_") and f.endswith("_sed.dat")]
+    assert len(expected) == 2
+    for f in expected:
+        assert _same_file(golden(f), str(tmp_path / f)), f
