@@ -139,6 +139,8 @@ namespace
         std::vector<NodeRec> internals;  // by internal index
         std::vector<int32_t> nbrStart, nbrList;
         uint32_t rootLink{0};
+        int coarseLevel{0};
+        std::vector<uint32_t> coarse;    // [2^Lc]^3 (z, y, x): link of the covering node at level <= Lc
     };
 
     int buildTree(const pmc_grid& g, const double* density, TreeBuild& T)
@@ -196,6 +198,16 @@ namespace
                 return fail(PMC_ERR_UNSUPPORTED,
                             "octree node boxes are not consistent with a dyadic coordinate table (node " + std::to_string(id) + ")");
         }
+        // entries that are no node's wall (inside coarse leaves) get the dyadic midpoints: no decision ever depends on
+        // them, but the table becomes strictly monotonic, which the index search of topDown (pmc_walk.inc) relies on
+        for (int axis = 0; axis < 3; ++axis)
+            for (int size = 1 << maxLevel; size >= 2; size >>= 1)
+                for (int lo = 0; lo + size <= (1 << maxLevel); lo += size)
+                {
+                    double& mid = T.table[size_t(axis) * T.tabn + lo + size / 2];
+                    if (std::isnan(mid))
+                        mid = (T.table[size_t(axis) * T.tabn + lo] + T.table[size_t(axis) * T.tabn + lo + size]) / 2.;
+                }
         // box code (pmc_device.h LeafRec::code): LDS byte offsets of the three lower wall entries + size exponent
         auto code = [&](int id) -> uint64_t {
             const uint64_t ox = 8ull * uint64_t(fx[id]);
@@ -211,6 +223,29 @@ namespace
                                               : (e | (uint32_t(internalIndex[id]) << 4) | PMC_LINK_NODE);
         };
         T.rootLink = linkOf(0);
+        // top-down search table (pmc_walk.inc topDown): per cell of the regular grid of level Lc the node of level Lc
+        // that covers it, or the coarser leaf
+        {
+            const int lc = std::min(maxLevel, 6);
+            T.coarseLevel = lc;
+            const int nc = 1 << lc;
+            T.coarse.resize(size_t(nc) * nc * nc);
+            for (int cz = 0; cz < nc; ++cz)
+                for (int cy = 0; cy < nc; ++cy)
+                    for (int cx = 0; cx < nc; ++cx)
+                    {
+                        const int px = cx << (maxLevel - lc), py = cy << (maxLevel - lc), pz = cz << (maxLevel - lc);
+                        int node = 0;
+                        while (g.node_first_child[node] >= 0 && g.node_level[node] < lc)
+                        {
+                            const int half = 1 << (maxLevel - g.node_level[node] - 1);
+                            const int l = ((px - fx[node]) >= half ? 1 : 0) + ((py - fy[node]) >= half ? 2 : 0)
+                                          + ((pz - fz[node]) >= half ? 4 : 0);
+                            node = g.node_first_child[node] + l;
+                        }
+                        T.coarse[(size_t(cz) * nc + cy) * nc + cx] = linkOf(node);
+                    }
+        }
 
         // the node at level <= level(id) that covers the region just across `wall` of node id (-1: outside the grid)
         auto covering = [&](int id, int wall) -> int {
@@ -495,6 +530,8 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if ((rc = ctx->upload(T.leaves.data(), T.leaves.size(), &D.leaves))) return bail(rc);
         if ((rc = ctx->upload(T.axis.data(), T.axis.size(), &D.axis_tab))) return bail(rc);
         if ((rc = ctx->upload(T.internals.data(), T.internals.size(), &D.nodes))) return bail(rc);
+        D.coarse_level = T.coarseLevel;
+        if ((rc = ctx->upload(T.coarse.data(), T.coarse.size(), &D.coarse_tab))) return bail(rc);
         if ((rc = ctx->upload(T.nbrStart.data(), T.nbrStart.size(), &D.nbr_start))) return bail(rc);
         if ((rc = ctx->upload(T.nbrList.data(), T.nbrList.size(), &D.nbr_list))) return bail(rc);
         D.lds_grid_len = 3 * T.tabn;
@@ -922,9 +959,9 @@ int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out)
     if (getenv("PMC_DEBUG_DUMP")) fprintf(stderr, "PMC_DEBUG flush: short %llu long %llu short_ell_neg %llu\n", host[60], host[61], host[62]);
     if (getenv("PMC_PROFILE_DUMP"))
     {
-        fprintf(stderr, "PMC_PROFILE transition (wave cycles): stage %llu sort %llu peel %llu pass1 %llu pass2 %llu start %llu append %llu flush %llu\n",
+        fprintf(stderr, "PMC_PROFILE transition (wave cycles): stage %llu mode-load %llu cycle-tail %llu append %llu loads+detect %llu scatter %llu start-cycle %llu flush %llu\n",
                 host[40], host[41], host[42], host[43], host[44], host[45], host[46], host[47]);
-        fprintf(stderr, "PMC_PROFILE launch (wave cycles): stage %llu list %llu stats %llu launch %llu start %llu append %llu flush %llu\n",
+        fprintf(stderr, "PMC_PROFILE launch (wave cycles): stage %llu list %llu stats-flush %llu start-cycle %llu draw+sample %llu - %llu flush %llu\n",
                 host[48], host[49], host[50], host[51], host[52], host[53], host[54]);
     }
     if (getenv("PMC_PROFILE_DUMP"))

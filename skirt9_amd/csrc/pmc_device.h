@@ -149,6 +149,8 @@ struct DevScene
     double  fine_scale[3];       // octree: 2^lmax / extent per axis (position -> finest-level cell index)
     uint32_t tab_stride_bytes;   // octree: bytes per axis of the coordinate table = 8 * ((1 << lmax) + 1)
     const double* coord_tab;     // [3][(1<<lmax)+1]
+    int32_t coarse_level;        // octree: level Lc = min(lmax, 6) of the top-down search table
+    const uint32_t* coarse_tab;  // [2^Lc][2^Lc][2^Lc] (z, y, x): link of the node at level <= Lc that covers the coarse cell
     const LeafRec* leaves;
     const AxisRec* axis_tab;     // [3][num_cells]: the walk step's gather
     const NodeRec* nodes;
