@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 3
+#define PMC_ABI_VERSION 4
 
 enum { PMC_OK = 0, PMC_ERR_INVALID = -1, PMC_ERR_UNSUPPORTED = -2, PMC_ERR_DEVICE = -3, PMC_ERR_NOMEM = -4 };
 
@@ -227,6 +227,13 @@ typedef struct pmc_scene
     int32_t     num_instruments;
     const pmc_instrument* instruments;
     pmc_radiation_field radiation_field;
+    /* a source system with more than one source (SourceSystem.cpp:75-107).  num_sources <= 1: `source` above is the
+       only source.  num_sources > 1: sources[0..num_sources) replace it (each with its own packet_luminosity =
+       L/Npp * Lv[h]/Wv[h]), and history index h is launched by source i with source_first[i] <= h < source_first[i+1]
+       (SourceSystem::_Iv for the segment's number of packets; num_sources + 1 entries).  At most 8 sources. */
+    int32_t         num_sources;
+    const pmc_source* sources;
+    const uint64_t*  source_first;
 } pmc_scene;
 
 /* counted work, accumulated over all pmc_run_primary calls since create/reset (roofline inputs) */

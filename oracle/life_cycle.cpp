@@ -675,7 +675,11 @@ namespace
         //      NormalizedSource.cpp:73-110, PointSource.cpp:32-43, GeometricSource.cpp:66-82, PhotonPacket.cpp:18-40)
         void launch(Packet& pp, uint64_t historyIndex)
         {
-            const pmc_source& s = sc.source;
+            // SourceSystem::launch (SourceSystem.cpp:100-107): upper_bound of the history index in the _Iv boundaries
+            int si = 0;
+            if (sc.num_sources > 1)
+                while (si + 1 < sc.num_sources && historyIndex >= sc.source_first[si + 1]) ++si;
+            const pmc_source& s = sc.num_sources > 1 ? sc.sources[si] : sc.source;
             double L = s.packet_luminosity;
             double lambda, w;
             if (s.lambda_mode == PMC_LAMBDA_OLIGO)

@@ -555,51 +555,63 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     D.min_scatt_events = scene->options.min_scatt_events;
     D.path_length_bias = scene->options.path_length_bias;
 
-    // ---- source
-    const pmc_source& src = scene->source;
-    D.source_kind = src.kind;
-    std::memcpy(D.src_pos, src.position, sizeof(D.src_pos));
-    D.reff = src.reff;
-    D.sersic_n = src.sersic_n;
-    std::memcpy(D.src_box, src.box, sizeof(D.src_box));
-    D.packet_luminosity = src.packet_luminosity;
-    D.lambda_mode = src.lambda_mode;
-    D.num_oligo = src.num_oligo;
-    D.lambda_bias = src.lambda_bias;
-    D.num_sed = src.num_sed;
-    D.bias_kind = src.bias_kind;
-    D.bias_min = src.bias_min;
-    D.bias_max = src.bias_max;
-    D.sed_kind = src.sed_kind;
-    D.sed_f1 = src.sed_f1;
-    D.sed_f2 = src.sed_f2;
-    D.sed_ltot = src.sed_ltot;
+    // ---- sources
+    const int numSources = scene->num_sources > 1 ? scene->num_sources : 1;
+    if (numSources > PMC_MAX_SOURCES) return bail(fail(PMC_ERR_UNSUPPORTED, "more than " + std::to_string(PMC_MAX_SOURCES) + " sources"));
+    if (numSources > 1 && (!scene->sources || !scene->source_first)) return bail(fail(PMC_ERR_INVALID, "source tables missing"));
+    D.num_sources = numSources;
     D.lds_src_off = transDoubles;
-    if (src.kind == PMC_SOURCE_SERSIC)
+    for (int si = 0; si < numSources; ++si)
     {
-        if (src.sersic_n < 2) return bail(fail(PMC_ERR_INVALID, "Sersic source without tables"));
-        if ((rc = ctx->upload(src.sersic_s, src.sersic_n, &D.sersic_s))) return bail(rc);
-        if ((rc = ctx->upload(src.sersic_M, src.sersic_n, &D.sersic_M))) return bail(rc);
-        transDoubles += 2 * src.sersic_n;
+        const pmc_source& src = numSources > 1 ? scene->sources[si] : scene->source;
+        DevSource& Q = D.src[si];
+        D.src_first[si] = numSources > 1 ? scene->source_first[si] : 0;
+        Q.source_kind = src.kind;
+        std::memcpy(Q.src_pos, src.position, sizeof(Q.src_pos));
+        Q.reff = src.reff;
+        Q.sersic_n = src.sersic_n;
+        std::memcpy(Q.src_box, src.box, sizeof(Q.src_box));
+        Q.packet_luminosity = src.packet_luminosity;
+        Q.lambda_mode = src.lambda_mode;
+        Q.num_oligo = src.num_oligo;
+        Q.lambda_bias = src.lambda_bias;
+        Q.num_sed = src.num_sed;
+        Q.bias_kind = src.bias_kind;
+        Q.bias_min = src.bias_min;
+        Q.bias_max = src.bias_max;
+        Q.sed_kind = src.sed_kind;
+        Q.sed_f1 = src.sed_f1;
+        Q.sed_f2 = src.sed_f2;
+        Q.sed_ltot = src.sed_ltot;
+        if (src.kind == PMC_SOURCE_SERSIC)
+        {
+            if (src.sersic_n < 2) return bail(fail(PMC_ERR_INVALID, "Sersic source without tables"));
+            if ((rc = ctx->upload(src.sersic_s, src.sersic_n, &Q.sersic_s))) return bail(rc);
+            if ((rc = ctx->upload(src.sersic_M, src.sersic_n, &Q.sersic_M))) return bail(rc);
+            if (numSources == 1) transDoubles += 2 * src.sersic_n;
+        }
+        else if (src.kind != PMC_SOURCE_POINT && src.kind != PMC_SOURCE_UNIFORM_BOX && src.kind != PMC_SOURCE_EXP_DISK
+                 && src.kind != PMC_SOURCE_PLUMMER)
+            return bail(fail(PMC_ERR_UNSUPPORTED, "unsupported source kind"));
+        if (src.lambda_mode == PMC_LAMBDA_OLIGO)
+        {
+            if (src.num_oligo < 1) return bail(fail(PMC_ERR_INVALID, "oligochromatic source without wavelengths"));
+            if ((rc = ctx->upload(src.oligo_lambda, src.num_oligo, &Q.oligo_lambda))) return bail(rc);
+            if ((rc = ctx->upload(src.oligo_weight, src.num_oligo, &Q.oligo_weight))) return bail(rc);
+        }
+        else if (src.lambda_mode == PMC_LAMBDA_TABULATED)
+        {
+            if (src.num_sed < 2) return bail(fail(PMC_ERR_INVALID, "tabulated source without SED table"));
+            if ((rc = ctx->upload(src.sed_lambda, src.num_sed, &Q.sed_lambda))) return bail(rc);
+            if ((rc = ctx->upload(src.sed_p, src.num_sed, &Q.sed_p))) return bail(rc);
+            if ((rc = ctx->upload(src.sed_P, src.num_sed, &Q.sed_P))) return bail(rc);
+        }
+        else
+            return bail(fail(PMC_ERR_UNSUPPORTED, "unsupported wavelength sampling mode"));
     }
-    else if (src.kind != PMC_SOURCE_POINT && src.kind != PMC_SOURCE_UNIFORM_BOX && src.kind != PMC_SOURCE_EXP_DISK
-             && src.kind != PMC_SOURCE_PLUMMER)
-        return bail(fail(PMC_ERR_UNSUPPORTED, "unsupported source kind"));
-    if (src.lambda_mode == PMC_LAMBDA_OLIGO)
-    {
-        if (src.num_oligo < 1) return bail(fail(PMC_ERR_INVALID, "oligochromatic source without wavelengths"));
-        if ((rc = ctx->upload(src.oligo_lambda, src.num_oligo, &D.oligo_lambda))) return bail(rc);
-        if ((rc = ctx->upload(src.oligo_weight, src.num_oligo, &D.oligo_weight))) return bail(rc);
-    }
-    else if (src.lambda_mode == PMC_LAMBDA_TABULATED)
-    {
-        if (src.num_sed < 2) return bail(fail(PMC_ERR_INVALID, "tabulated source without SED table"));
-        if ((rc = ctx->upload(src.sed_lambda, src.num_sed, &D.sed_lambda))) return bail(rc);
-        if ((rc = ctx->upload(src.sed_p, src.num_sed, &D.sed_p))) return bail(rc);
-        if ((rc = ctx->upload(src.sed_P, src.num_sed, &D.sed_P))) return bail(rc);
-    }
-    else
-        return bail(fail(PMC_ERR_UNSUPPORTED, "unsupported wavelength sampling mode"));
+    D.src_first[numSources] = numSources > 1 ? scene->source_first[numSources] : ~0ull;
+    for (int si = 1; si < numSources; ++si)
+        if (D.src[si].lambda_mode != D.src[0].lambda_mode) return bail(fail(PMC_ERR_INVALID, "sources with different wavelength regimes"));
 
     // ---- instruments and frame layout
     D.num_instruments = scene->num_instruments;

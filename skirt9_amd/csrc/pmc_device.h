@@ -135,6 +135,33 @@ struct TaskArrays
 #define PMC_TASK_NONE 0xFFFFFFFFu
 #define PMC_LAUNCH_SHARDS 64
 
+#define PMC_MAX_SOURCES 8
+// one source of the source system: spatial sampling, luminosity per packet, wavelength sampling (pmc.h pmc_source)
+struct DevSource
+{
+    int32_t source_kind;
+    double  src_pos[3];
+    double  reff;
+    int32_t sersic_n;
+    const double* sersic_s;
+    const double* sersic_M;
+    double  src_box[6];
+    double  packet_luminosity;
+    int32_t lambda_mode;
+    int32_t num_oligo;
+    const double* oligo_lambda;
+    const double* oligo_weight;
+    double  lambda_bias;
+    int32_t num_sed;
+    const double* sed_lambda;
+    const double* sed_p;
+    const double* sed_P;
+    int32_t bias_kind;
+    double  bias_min, bias_max;
+    int32_t sed_kind;
+    double  sed_f1, sed_f2, sed_ltot;
+};
+
 struct DevScene
 {
     // ---- grid
@@ -180,28 +207,10 @@ struct DevScene
     double  min_weight_reduction;
     int32_t min_scatt_events;
     double  path_length_bias;
-    // ---- source
-    int32_t source_kind;
-    double  src_pos[3];
-    double  reff;
-    int32_t sersic_n;
-    const double* sersic_s;
-    const double* sersic_M;
-    double  src_box[6];
-    double  packet_luminosity;
-    int32_t lambda_mode;
-    int32_t num_oligo;
-    const double* oligo_lambda;
-    const double* oligo_weight;
-    double  lambda_bias;
-    int32_t num_sed;
-    const double* sed_lambda;
-    const double* sed_p;
-    const double* sed_P;
-    int32_t bias_kind;
-    double  bias_min, bias_max;
-    int32_t sed_kind;
-    double  sed_f1, sed_f2, sed_ltot;
+    // ---- sources (SourceSystem.cpp:100-107: history index h belongs to source i with src_first[i] <= h < src_first[i+1])
+    int32_t num_sources;
+    DevSource src[PMC_MAX_SOURCES];
+    uint64_t src_first[PMC_MAX_SOURCES + 1];
     // ---- instruments
     int32_t num_instruments;
     DevInstrument inst[PMC_MAX_INSTRUMENTS];

@@ -188,8 +188,12 @@ namespace skh
         _oligoWavelengths = rd.list(*ss, "wavelengths", "wavelength", "0.55 micron");
         _sourceBias = rd.number(*ss, "sourceBias", "0.5");
         auto sources = ss->items("sources");
-        if (sources.size() != 1) unsupported("a source system with " + std::to_string(sources.size()) + " sources");
-        const XmlElement& src = *sources[0];
+        if (sources.empty() || sources.size() > 8) unsupported("a source system with " + std::to_string(sources.size()) + " sources");
+        for (const XmlElement* srcElement : sources)
+        {
+        const XmlElement& src = *srcElement;
+        _sources.emplace_back();
+        SourceModel& _source = _sources.back();
         _source.type = src.name;
         _source.sourceWeight = rd.number(src, "sourceWeight", "1");
         _source.wavelengthBias = rd.number(src, "wavelengthBias", "0.5");
@@ -295,6 +299,7 @@ namespace skh
             else if (bd->name != "DefaultWavelengthDistribution")
                 unsupported("wavelength bias distribution " + bd->name);
         }
+        }  // sources
 
         // ---- medium system
         const XmlElement* ms = sim.item("mediumSystem");
@@ -640,7 +645,21 @@ namespace skh
             }
         }
 
-        // ---- source: luminosity and wavelength sampling tables
+        // ---- sources: luminosity and wavelength sampling tables
+        buildScene();
+        const int Ns = static_cast<int>(_sources.size());
+        _sourceTables.assign(Ns, SourceTables());
+        _sceneSources.assign(Ns, pmc_source());
+        for (int hs = 0; hs < Ns; ++hs)
+        {
+        SourceModel& _source = _sources[hs];
+        Array& _sedLambda = _sourceTables[hs].sedLambda;
+        Array& _sedp = _sourceTables[hs].sedp;
+        Array& _sedP = _sourceTables[hs].sedP;
+        Array& _oligoWeight = _sourceTables[hs].oligoWeight;
+        double& _sourceLuminosity = _sourceTables[hs].luminosity;
+        pmc_source& flat = _sceneSources[hs];
+        flattenSourceGeometry(_source, flat);
         // BlackBodySED (BlackBodySED.cpp:12-39) over the normalisation range = source range
         const double h = constants::h, c = constants::c, k = constants::k;
         double f1 = h * c / (k * _source.temperature);
@@ -705,19 +724,6 @@ namespace skh
             _sourceLuminosity = _source.integratedLuminosity / L;
         }
 
-        // SourceSystem::setupSelfAfter / prepareForLaunch / launch for one source (SourceSystem.cpp:14-40,75-112)
-        double Lsys = _sourceLuminosity;  // _Lv.sum()
-        double Lv0 = _sourceLuminosity / Lsys;
-        double wv0 = _source.sourceWeight;
-        double wLv0 = wv0 * Lv0;
-        double xi = _sourceBias;
-        double Wv0 = (1 - xi) * wLv0 / wLv0 + xi * wv0 / wv0;
-        double Lpp = Lsys / _numPackets;
-        double launchWeight = Lv0 / Wv0;
-
-        buildScene();
-        _scene.source.packet_luminosity = _numPackets ? Lpp * launchWeight : 0.;
-
         if (_oligo)
         {
             // NormalizedSource::launch with xi = 1 and OligoWavelengthDistribution (NormalizedSource.cpp:26-29,73-110;
@@ -737,23 +743,23 @@ namespace skh
                     _oligoWeight[i] = s / ((1 - xil) * s + xil * b);
                 }
             }
-            _scene.source.lambda_mode = PMC_LAMBDA_OLIGO;
-            _scene.source.num_oligo = static_cast<int32_t>(lam.size());
-            _scene.source.oligo_lambda = lam.data();
-            _scene.source.oligo_weight = _oligoWeight.data();
+            flat.lambda_mode = PMC_LAMBDA_OLIGO;
+            flat.num_oligo = static_cast<int32_t>(lam.size());
+            flat.oligo_lambda = lam.data();
+            flat.oligo_weight = _oligoWeight.data();
         }
         else
         {
-            _scene.source.lambda_mode = PMC_LAMBDA_TABULATED;
-            _scene.source.lambda_bias = _source.wavelengthBias;
-            _scene.source.num_sed = static_cast<int32_t>(_sedLambda.size());
-            _scene.source.sed_lambda = _sedLambda.data();
-            _scene.source.sed_p = _sedp.data();
-            _scene.source.sed_P = _sedP.data();
-            _scene.source.sed_kind = tabulated ? PMC_SED_TABULATED : PMC_SED_BLACKBODY;
-            _scene.source.sed_f1 = f1;
-            _scene.source.sed_f2 = f2;
-            _scene.source.sed_ltot = Ltot;
+            flat.lambda_mode = PMC_LAMBDA_TABULATED;
+            flat.lambda_bias = _source.wavelengthBias;
+            flat.num_sed = static_cast<int32_t>(_sedLambda.size());
+            flat.sed_lambda = _sedLambda.data();
+            flat.sed_p = _sedp.data();
+            flat.sed_P = _sedP.data();
+            flat.sed_kind = tabulated ? PMC_SED_TABULATED : PMC_SED_BLACKBODY;
+            flat.sed_f1 = f1;
+            flat.sed_f2 = f2;
+            flat.sed_ltot = Ltot;
             // bias distribution range: Default = source range; Log/Lin = configured range intersected with source range
             double lo = sourceMin, hi = sourceMax;
             if (_source.biasDistType != "DefaultWavelengthDistribution")
@@ -762,41 +768,57 @@ namespace skh
                 hi = std::min(hi, _source.biasMax);
                 if (!(lo < hi)) throw std::runtime_error("Wavelength distribution range does not overlap source wavelength range");
             }
-            _scene.source.bias_kind = _source.biasDistType == "LinWavelengthDistribution" ? PMC_BIAS_LIN : PMC_BIAS_LOG;
-            _scene.source.bias_min = lo;
-            _scene.source.bias_max = hi;
+            flat.bias_kind = _source.biasDistType == "LinWavelengthDistribution" ? PMC_BIAS_LIN : PMC_BIAS_LOG;
+            flat.bias_min = lo;
+            flat.bias_max = hi;
+        }
+        }  // sources
+
+        // SourceSystem::setupSelfAfter / prepareForLaunch / launch (SourceSystem.cpp:14-40,75-107): normalised luminosities
+        // _Lv, launch weights _Wv (composite bias), history index boundaries _Iv, luminosity per packet
+        {
+            double Lsys = 0.;
+            for (const SourceTables& t : _sourceTables) Lsys += t.luminosity;
+            if (!(Lsys > 0.)) throw std::runtime_error("The total luminosity of the source system is zero");
+            std::vector<double> Lv(Ns), wv(Ns), wLv(Ns), Wv(Ns);
+            for (int hs = 0; hs < Ns; ++hs) Lv[hs] = _sourceTables[hs].luminosity;
+            for (int hs = 0; hs < Ns; ++hs) Lv[hs] /= Lsys;
+            for (int hs = 0; hs < Ns; ++hs) wv[hs] = _sources[hs].sourceWeight;
+            double wLsum = 0., wsum = 0.;
+            for (int hs = 0; hs < Ns; ++hs)
+            {
+                wLv[hs] = wv[hs] * Lv[hs];
+                wLsum += wLv[hs];
+                wsum += wv[hs];
+            }
+            const double xi = _sourceBias;
+            for (int hs = 0; hs < Ns; ++hs) Wv[hs] = (1 - xi) * wLv[hs] / wLsum + xi * wv[hs] / wsum;
+            _sourceFirst.assign(Ns + 1, 0);
+            double W = 0.;
+            for (int hs = 1; hs < Ns; ++hs)
+            {
+                // track the cumulative normalised weight as a floating point number and limit the index to numPackets
+                W += Wv[hs - 1];
+                _sourceFirst[hs] = std::min(_numPackets, static_cast<uint64_t>(std::round(W * _numPackets)));
+            }
+            _sourceFirst[Ns] = _numPackets;
+            const double Lpp = Lsys / _numPackets;
+            for (int hs = 0; hs < Ns; ++hs) _sceneSources[hs].packet_luminosity = _numPackets ? Lpp * (Lv[hs] / Wv[hs]) : 0.;
+        }
+        _scene.source = _sceneSources[0];
+        if (Ns > 1)
+        {
+            _scene.num_sources = Ns;
+            _scene.sources = _sceneSources.data();
+            _scene.source_first = _sourceFirst.data();
         }
     }
 
     // ================================================================ scene flattening
 
-    void Simulation::buildScene()
+    // spatial part of one source (PointSource.cpp:32-43, GeometricSource.cpp:66-82 with the geometry's generatePosition)
+    void Simulation::flattenSourceGeometry(const SourceModel& _source, pmc_source& s) const
     {
-        std::memset(&_scene, 0, sizeof(_scene));
-        _scene.abi_version = PMC_ABI_VERSION;
-
-        pmc_grid& g = _scene.grid;
-        g.xmin = _grid->extent.xmin;
-        g.ymin = _grid->extent.ymin;
-        g.zmin = _grid->extent.zmin;
-        g.xmax = _grid->extent.xmax;
-        g.ymax = _grid->extent.ymax;
-        g.zmax = _grid->extent.zmax;
-        g.eps = 1e-12 * _grid->extent.diagonal();
-        g.num_cells = _grid->numCells();
-        _grid->fill(g);
-
-        pmc_medium& m = _scene.medium;
-        m.number_density = _density.data();
-        m.num_lambda = static_cast<int32_t>(_medium->mix->lambdaBorder.size());
-        m.lambda_border = _medium->mix->lambdaBorder.data();
-        m.sigma_ext = _medium->mix->sigmaExt.data();
-        m.sigma_sca = _medium->mix->sigmaSca.data();
-        m.asymmpar = _medium->mix->asymmpar.data();
-
-        _scene.options = _options;
-
-        pmc_source& s = _scene.source;
         if (_source.type == "PointSource")
         {
             s.kind = PMC_SOURCE_POINT;
@@ -829,6 +851,33 @@ namespace skh
             s.kind = PMC_SOURCE_PLUMMER;
             s.box[0] = plummer->scaleLength();
         }
+    }
+
+    void Simulation::buildScene()
+    {
+        std::memset(&_scene, 0, sizeof(_scene));
+        _scene.abi_version = PMC_ABI_VERSION;
+
+        pmc_grid& g = _scene.grid;
+        g.xmin = _grid->extent.xmin;
+        g.ymin = _grid->extent.ymin;
+        g.zmin = _grid->extent.zmin;
+        g.xmax = _grid->extent.xmax;
+        g.ymax = _grid->extent.ymax;
+        g.zmax = _grid->extent.zmax;
+        g.eps = 1e-12 * _grid->extent.diagonal();
+        g.num_cells = _grid->numCells();
+        _grid->fill(g);
+
+        pmc_medium& m = _scene.medium;
+        m.number_density = _density.data();
+        m.num_lambda = static_cast<int32_t>(_medium->mix->lambdaBorder.size());
+        m.lambda_border = _medium->mix->lambdaBorder.data();
+        m.sigma_ext = _medium->mix->sigmaExt.data();
+        m.sigma_sca = _medium->mix->sigmaSca.data();
+        m.asymmpar = _medium->mix->asymmpar.data();
+
+        _scene.options = _options;
 
         // instruments (DistantInstrument.cpp:13-51, FrameInstrument.cpp:12-33, FullInstrument.cpp:11-17)
         _pmcInstruments.assign(_instruments.size(), pmc_instrument{});

@@ -54,7 +54,8 @@ namespace skh
         const SpatialGrid& grid() const { return *_grid; }
         const Medium& medium() const { return *_medium; }
         const Array& numberDensity() const { return _density; }
-        const SourceModel& source() const { return _source; }
+        const SourceModel& source(int h = 0) const { return _sources[h]; }
+        int numSources() const { return static_cast<int>(_sources.size()); }
 
         // optional overrides applied before setup()
         void setNumPackets(uint64_t n) { _numPackets = n; }
@@ -67,6 +68,7 @@ namespace skh
         Simulation() {}
         void parse(const XmlElement& root);
         void buildScene();
+        void flattenSourceGeometry(const SourceModel& source, pmc_source& flat) const;
 
         std::string _prefix;
         std::string _inputPath{"."};
@@ -79,7 +81,7 @@ namespace skh
         // source system
         double _ssMinWavelength{0.09e-6}, _ssMaxWavelength{100e-6}, _sourceBias{0.5};
         Array _oligoWavelengths;
-        SourceModel _source;
+        std::vector<SourceModel> _sources;
         // medium system
         pmc_options _options{};
         int _numDensitySamples{100};
@@ -97,8 +99,15 @@ namespace skh
         std::unique_ptr<WavelengthGrid> _oligoGrid;       // OligoWavelengthGrid
         std::vector<InstrumentModel> _instruments;
         // derived tables referenced by the scene
-        Array _oligoWeight, _sedLambda, _sedp, _sedP;
-        double _sourceLuminosity{0};
+        // per source: wavelength sampling tables and luminosity; flattened sources and the history index boundaries
+        struct SourceTables
+        {
+            Array oligoWeight, sedLambda, sedp, sedP;
+            double luminosity{0};
+        };
+        std::vector<SourceTables> _sourceTables;
+        std::vector<pmc_source> _sceneSources;
+        std::vector<uint64_t> _sourceFirst;
         std::vector<pmc_instrument> _pmcInstruments;
         std::vector<pmc_frame_layout> _layouts;
         int64_t _frameSize{0};
