@@ -184,6 +184,9 @@ typedef struct pmc_instrument
     int32_t        num_border;
     const double*  border;
     const int32_t* ellv;                 /* num_border + 1 */
+    /* ApertureInstrument::isInsideAperture (ApertureInstrument.cpp:22-43) for an SEDInstrument with a finite aperture:
+       a packet whose position projects farther than the radius from the line of sight is not detected (0: no aperture) */
+    double         aperture_radius2;
 } pmc_instrument;
 
 /* Layout of one instrument's detector arrays inside the frame buffer (doubles).  Components c:

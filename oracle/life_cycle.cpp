@@ -1086,6 +1086,14 @@ namespace
         {
             const pmc_instrument& ins = sc.instruments[instrument];
             const pmc_frame_layout& L = layouts[instrument];
+            // ApertureInstrument::isInsideAperture (ApertureInstrument.cpp:22-43), tested by SEDInstrument::detect
+            if (ins.aperture_radius2)
+            {
+                double xpp = -ins.sinphi * ppp.r.x + ins.cosphi * ppp.r.y;
+                double ypp = -ins.cosphi * ins.costheta * ppp.r.x - ins.sinphi * ins.costheta * ppp.r.y + ins.sintheta * ppp.r.z;
+                double radius2 = xpp * xpp + ypp * ypp;
+                if (radius2 > ins.aperture_radius2) return;
+            }
             if (!ins.include_flux_density && l < 0) return;
             double wavelength = ppp.lambda * (1. + ins.redshift);
             // DisjointWavelengthGrid::bins (DisjointWavelengthGrid.cpp:320-345)

@@ -633,6 +633,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         d.record_components = I.record_components;
         d.num_levels = I.num_scattering_levels;
         d.record_stats = I.record_statistics;
+        d.aperture_r2 = I.aperture_radius2;
         if (I.redshift != 0.) return bail(fail(PMC_ERR_UNSUPPORTED, "instrument redshift is not supported"));
         d.num_lambda = I.num_lambda;
         d.num_border = I.num_border;

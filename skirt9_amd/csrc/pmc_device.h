@@ -67,6 +67,7 @@ struct DevInstrument
     int32_t nxp, nyp;
     int32_t same_observer;
     int32_t include_sed, include_ifu, record_components, num_levels, record_stats;
+    double aperture_r2;  // SEDInstrument aperture radius squared (0: none)
     int32_t num_lambda, num_border;
     const double* border;   // device
     const int32_t* ellv;    // device

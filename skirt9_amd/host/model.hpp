@@ -413,6 +413,7 @@ namespace skh
         double distance{0}, inclination{0}, azimuth{0}, roll{0};
         double fieldOfViewX{0}, fieldOfViewY{0}, centerX{0}, centerY{0};
         int numPixelsX{250}, numPixelsY{250};
+        double radius{0};  // SEDInstrument: aperture radius (0: none)
         bool recordComponents{false}, recordPolarization{false}, recordStatistics{false};
         int numScatteringLevels{0};
         std::unique_ptr<WavelengthGrid> ownGrid;  // instrument-specific grid (panchromatic only)

@@ -484,9 +484,9 @@ namespace skh
             ins.type = ie->name;
             if (ie->name != "FrameInstrument" && ie->name != "FullInstrument" && ie->name != "SEDInstrument")
                 unsupported("instrument " + ie->name);
-            // SEDInstrument (SEDInstrument.cpp:11-22, ApertureInstrument.cpp:11-37): the flux density only; a finite aperture
-            // radius is not supported
-            if (ie->name == "SEDInstrument" && rd.quantity(*ie, "radius", "length", "0") != 0.) unsupported("SEDInstrument with an aperture radius");
+            // SEDInstrument (SEDInstrument.cpp:11-22, ApertureInstrument.cpp:11-43): the flux density only, optionally within
+            // an aperture radius around the line of sight
+            if (ie->name == "SEDInstrument") ins.radius = rd.quantity(*ie, "radius", "length", "0");
             ins.name = ie->attr("instrumentName");
             ins.distance = rd.quantity(*ie, "distance", "distance");
             ins.inclination = rd.quantity(*ie, "inclination", "posangle", "0 deg");
@@ -923,6 +923,7 @@ namespace skh
                 p.xpmin = p.ypmin = -0.25 * DBL_MAX;
                 p.xpsiz = p.ypsiz = 0.5 * DBL_MAX;
             }
+            p.aperture_radius2 = ins.radius * ins.radius;
             p.record_components = ins.recordComponents;  // a medium is always present on this path
             p.num_scattering_levels = ins.recordComponents ? ins.numScatteringLevels : 0;
             p.record_statistics = ins.recordStatistics;
