@@ -383,10 +383,94 @@ namespace skh
 
     void CartesianSpatialGrid::setup()
     {
-        // LinMesh::mesh (LinMesh.cpp:11-16) scaled as CartesianSpatialGrid.cpp:22-24
-        auto build = [](Array& v, int n, double lo, double hi) {
+        // Mesh::mesh of the configured class on [0,1] (LinMesh.cpp:11-16, PowMesh.cpp:11-19, SymPowMesh.cpp:11-19,
+        // LogMesh.cpp:11-19, SymLogMesh.cpp:11-42 with the grid builders of NR.hpp:203-320), scaled as
+        // CartesianSpatialGrid.cpp:22-24
+        auto meshOf = [](const MeshSpec& spec, int n) {
             Array tv;
-            nr::linearGrid(tv, 0.0, 1.0, n);
+            if (spec.type == "PowMesh" && n > 1)
+            {
+                // NR::buildPowerLawGrid
+                if (fabs(spec.ratio - 1.) < 1e-3)
+                    nr::linearGrid(tv, 0.0, 1.0, n);
+                else
+                {
+                    tv.resize(n + 1);
+                    double range = 1.0 - 0.0;
+                    double q = pow(spec.ratio, 1. / (n - 1));
+                    double qn = pow(q, n);
+                    for (int i = 0; i <= n; ++i) tv[i] = 0.0 + (1. - pow(q, i)) / (1. - qn) * range;
+                }
+            }
+            else if (spec.type == "SymPowMesh" && n > 2)
+            {
+                // NR::buildSymmetricPowerLawGrid
+                if (fabs(spec.ratio - 1.) < 1e-3)
+                    nr::linearGrid(tv, 0.0, 1.0, n);
+                else
+                {
+                    tv.resize(n + 1);
+                    const double xmin = 0.0, xmax = 1.0;
+                    double xc = 0.5 * (xmin + xmax);
+                    if (n % 2 == 0)
+                    {
+                        int M = n / 2;
+                        double q = pow(spec.ratio, 1.0 / (M - 1.0));
+                        double qM = pow(q, M);
+                        tv[M] = xc;
+                        for (int i = 1; i <= M; ++i)
+                        {
+                            double dxi = (1.0 - pow(q, i)) / (1.0 - qM) * 0.5 * (xmax - xmin);
+                            tv[M + i] = xc + dxi;
+                            tv[M - i] = xc - dxi;
+                        }
+                    }
+                    else
+                    {
+                        int M = (n + 1) / 2;
+                        double q = pow(spec.ratio, 1.0 / (M - 1.0));
+                        double qM = pow(q, M);
+                        for (int i = 1; i <= M; ++i)
+                        {
+                            double dxi = (0.5 + 0.5 * q - pow(q, i)) / (0.5 + 0.5 * q - qM) * 0.5 * (xmax - xmin);
+                            tv[M - 1 + i] = xc + dxi;
+                            tv[M - i] = xc - dxi;
+                        }
+                    }
+                }
+            }
+            else if (spec.type == "LogMesh" && n > 1)
+            {
+                // NR::buildZeroLogGrid(tv, centralBinFraction, 1, n)
+                tv.assign(n + 1, 0.);
+                double logxmin = log(spec.centralBinFraction);
+                double dlogx = log(1.0 / spec.centralBinFraction) / (n - 1);
+                for (int i = 0; i < n; i++) tv[i + 1] = exp(logxmin + i * dlogx);
+            }
+            else if (spec.type == "SymLogMesh" && n > 2)
+            {
+                // the rightmost half as NR::buildLogGrid(tmpv, centralBinFraction, 1, n2), mirrored
+                int n2 = (n - 1) / 2;
+                Array tmpv(n2 + 1);
+                double logxmin = log(spec.centralBinFraction);
+                double dlogx = log(1. / spec.centralBinFraction) / n2;
+                for (int i = 0; i <= n2; i++) tmpv[i] = exp(logxmin + i * dlogx);
+                tv.assign(n + 1, 0.);
+                int k = 0;
+                tv[k++] = 0.;
+                for (int i = n2 - 1; i >= 0; --i) tv[k++] = 0.5 - 0.5 * tmpv[i];
+                if (n % 2 == 0) tv[k++] = 0.5;
+                for (int i = 0; i <= n2 - 1; ++i) tv[k++] = 0.5 + 0.5 * tmpv[i];
+                tv[k++] = 1.;
+            }
+            else
+                nr::linearGrid(tv, 0.0, 1.0, (spec.type == "PowMesh" || spec.type == "LogMesh") ? 1 : n);
+            return tv;
+        };
+        const MeshSpec* specs = meshSpec;
+        int axis = 0;
+        auto build = [&](Array& v, int n, double lo, double hi) {
+            Array tv = meshOf(specs[axis++], n);
             v.resize(n + 1);
             for (int i = 0; i <= n; ++i) v[i] = tv[i] * (hi - lo) + lo;
         };

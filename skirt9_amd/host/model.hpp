@@ -298,6 +298,14 @@ namespace skh
     {
     public:
         int nx{0}, ny{0}, nz{0};
+        // the Mesh of every axis: LinMesh | PowMesh | SymPowMesh | LogMesh | SymLogMesh (mesh() of the class, on [0,1])
+        struct MeshSpec
+        {
+            std::string type{"LinMesh"};
+            double ratio{1};                  // PowMesh, SymPowMesh: last/first resp. outermost/innermost bin width
+            double centralBinFraction{1e-3};  // LogMesh, SymLogMesh
+        };
+        MeshSpec meshSpec[3];
         Array xv, yv, zv;
         void setup();
         int numCells() const override { return nx * ny * nz; }

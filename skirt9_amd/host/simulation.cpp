@@ -425,15 +425,23 @@ namespace skh
         {
             auto grid = std::make_unique<CartesianSpatialGrid>();
             grid->extent = extent;
+            int axisIndex = 0;
             auto bins = [&](const char* prop) {
+                CartesianSpatialGrid::MeshSpec& spec = grid->meshSpec[axisIndex++];
                 const XmlElement* mesh = ge->item(prop);
                 if (!mesh) return 100;  // Mesh default numBins
-                if (mesh->name != "LinMesh") unsupported("mesh " + mesh->name);
+                if (mesh->name != "LinMesh" && mesh->name != "PowMesh" && mesh->name != "SymPowMesh" && mesh->name != "LogMesh"
+                    && mesh->name != "SymLogMesh")
+                    unsupported("mesh " + mesh->name);
+                spec.type = mesh->name;
+                spec.ratio = rd.number(*mesh, "ratio", "1");
+                spec.centralBinFraction = rd.number(*mesh, "centralBinFraction", "1e-3");
                 return rd.integer(*mesh, "numBins", 100);
             };
             grid->nx = bins("meshX");
             grid->ny = bins("meshY");
             grid->nz = bins("meshZ");
+            if (grid->nx > 1023 || grid->ny > 1023 || grid->nz > 1023) unsupported("a Cartesian grid with more than 1023 bins per axis");
             _grid = std::move(grid);
         }
         else if (ge->name == "PolicyTreeSpatialGrid")

@@ -13,7 +13,7 @@ from skirt9_amd.host import Simulation, lib
 from skirt9_amd.host import Grid, Medium, SceneHead, scene_head  # noqa: E402,F401  (ctypes mirrors of include/pmc.h)
 
 
-@pytest.mark.parametrize("name,cells,nodes", [("cfg1", 32768, 0), ("cfg2small", 17592, 20105), ("cfg4small", 7274, 8313)])
+@pytest.mark.parametrize("name,cells,nodes", [("cfg1", 32768, 0), ("cfg1mesh", 31 * 24 * 20, 0), ("cfg1mesh2", 30 * 25 * 16, 0), ("cfg2small", 17592, 20105), ("cfg4small", 7274, 8313)])
 def test_cell_densities_bit_exact(name, cells, nodes):
     sim = Simulation(ski(name + ".ski")).setup()
     head = scene_head(sim)
@@ -80,7 +80,7 @@ def test_units_and_defaults(tmp_path):
 
 
 @pytest.mark.parametrize("old,new,message", [
-    ('<LinMesh numBins="32"/></meshX>', '<PowMesh numBins="32" ratio="2"/></meshX>', "PowMesh"),
+    ('<LinMesh numBins="32"/></meshX>', '<FileMesh filename="mesh.txt"/></meshX>', "FileMesh"),
     ("MeanListDustMix", "DraineLiDustMix", "DraineLiDustMix"),
     ('simulationMode="OligoExtinctionOnly"', 'simulationMode="DustEmission"', "simulationMode"),
     ('maxX="1 pc" minY', 'maxX="1 furlong" minY', "unit"),
