@@ -279,6 +279,150 @@ namespace skh
         return Vec3{r * k.x, r * k.y, r * k.z};
     }
 
+    // ================================================================ ShellGeometry, TorusGeometry, RingGeometry
+
+    namespace
+    {
+        // SpecialFunctions::gln2 (SpecialFunctions.cpp:815-818)
+        double gln2(double p, double x1, double x2) { return pow(x2, 1.0 - p) * special::gln(p, x1 / x2); }
+    }
+
+    ShellGeometry::ShellGeometry(double rmin, double rmax, double p) : _rmin(rmin), _rmax(rmax), _p(p)
+    {
+        if (_rmax <= _rmin) throw std::runtime_error("the outer radius of the shell should be larger than the inner radius");
+        _smin = special::gln(_p - 2.0, _rmin);
+        _sdiff = gln2(_p - 2.0, _rmax, _rmin);
+        _tmin = pow(_rmin, 3.0 - _p);
+        _tmax = pow(_rmax, 3.0 - _p);
+        _A = 0.25 / M_PI / _sdiff;
+    }
+    double ShellGeometry::density(Vec3 bfr) const
+    {
+        double r = sqrt(bfr.x * bfr.x + bfr.y * bfr.y + bfr.z * bfr.z);
+        if (r < _rmin || r > _rmax) return 0.0;
+        return _A * pow(r, -_p);
+    }
+    double ShellGeometry::Sigmar() const { return _A * gln2(_p, _rmax, _rmin); }
+    Vec3 ShellGeometry::generatePosition(Random& random) const
+    {
+        double X = random.uniform();
+        double r;
+        if (fabs(_p - 3.0) < 1e-2)
+            r = special::gexp(_p - 2.0, _smin + X * _sdiff);
+        else
+            r = pow((1.0 - X) * _tmin + X * _tmax, 1.0 / (3.0 - _p));
+        Vec3 k = random.direction();
+        return Vec3{r * k.x, r * k.y, r * k.z};
+    }
+
+    TorusGeometry::TorusGeometry(double p, double q, double Delta, double rmin, double rmax, bool rani, double rcut)
+        : _p(p), _q(q), _Delta(Delta), _rmin(rmin), _rmax(rmax), _rani(rani), _rcut(rcut)
+    {
+        _sinDelta = sin(_Delta);
+        _smin = special::gln(_p - 2.0, _rmin);
+        _sdiff = gln2(_p - 2.0, _rmax, _rmin);
+        _tmin = pow(_rmin, 3.0 - _p);
+        _tmax = pow(_rmax, 3.0 - _p);
+        if (_q > 1e-3)
+            _A = _q * 0.25 / M_PI / _sdiff / (1.0 - exp(-_q * _sinDelta));
+        else
+            _A = 0.25 / M_PI / _sdiff / _sinDelta;
+    }
+    double TorusGeometry::density(Vec3 bfr) const
+    {
+        // AxGeometry::density(Position) passes the cylindrical radius and the height (AxGeometry.cpp:11-17)
+        double R = sqrt(bfr.x * bfr.x + bfr.y * bfr.y), z = bfr.z;
+        double r = sqrt(R * R + z * z);
+        double costheta = z / r;
+        if (r >= _rmax) return 0.0;
+        if (_rani)
+        {
+            double rminani = _rmin * sqrt(6. / 7. * fabs(costheta) * (2. * fabs(costheta) + 1));
+            if (r <= rminani || r < _rcut) return 0.0;
+        }
+        else
+        {
+            if (r <= _rmin) return 0.0;
+        }
+        if (fabs(costheta) >= _sinDelta) return 0.0;
+        return _A * pow(r, -_p) * exp(-_q * fabs(costheta));
+    }
+    double TorusGeometry::SigmaR() const { return _A * gln2(_p, _rmax, _rmin); }
+    Vec3 TorusGeometry::generatePosition(Random& random) const
+    {
+        while (true)
+        {
+            double X = random.uniform();
+            double r;
+            if (fabs(_p - 3.0) < 1e-2)
+                r = special::gexp(_p - 2.0, _smin + X * _sdiff);
+            else
+                r = pow((1.0 - X) * _tmin + X * _tmax, 1.0 / (3.0 - _p));
+            X = random.uniform();
+            double costheta;
+            if (_q < 1e-3)
+                costheta = (1.0 - 2.0 * X) * _sinDelta;
+            else
+            {
+                double B = 1.0 - exp(-_q * _sinDelta);
+                costheta = (X < 0.5) ? -log(1.0 - B * (1.0 - 2.0 * X)) / _q : log(1.0 - B * (2.0 * X - 1.0)) / _q;
+            }
+            double theta = acos(costheta);
+            double phi = 2.0 * M_PI * random.uniform();
+            // Position(r, theta, phi, SPHERICAL) (Vec/Position.cpp)
+            double sintheta = sin(theta);
+            Vec3 pos{r * sintheta * cos(phi), r * sintheta * sin(phi), r * cos(theta)};
+            if (density(pos)) return pos;
+        }
+    }
+
+    RingGeometry::RingGeometry(double R0, double w, double hz) : _R0(R0), _w(w), _hz(hz)
+    {
+        double t = _R0 / _w / M_SQRT2;
+        double intz = 2.0 * _hz;
+        double intR = _w * _w * (exp(-t * t) + sqrt(M_PI) * t * (1.0 + erf(t)));
+        _A = 1.0 / (2.0 * M_PI * intz * intR);
+        int NR = 330;
+        nr::linearGrid(_Rv, std::max(0., _R0 - 8 * _w), _R0 + 8 * _w, NR - 1);
+        _Xv.resize(NR);
+        double sqrtpi = sqrt(M_PI);
+        for (int i = 0; i < NR; i++)
+        {
+            double R = _Rv[i];
+            double u = (_R0 - R) / _w / M_SQRT2;
+            _Xv[i] = 4.0 * M_PI * _A * _hz * _w * _w * (exp(-t * t) - exp(-u * u) + sqrtpi * t * (erf(t) - erf(u)));
+        }
+        _Xv[0] = 0.0;
+        _Xv[NR - 1] = 1.0;
+    }
+    double RingGeometry::density(Vec3 bfr) const
+    {
+        double R = sqrt(bfr.x * bfr.x + bfr.y * bfr.y), z = bfr.z;
+        double u = (R - _R0) / (M_SQRT2 * _w);
+        return _A * exp(-u * u) * exp(-fabs(z) / _hz);
+    }
+    double RingGeometry::SigmaR() const
+    {
+        double t = _R0 / (M_SQRT2 * _w);
+        return sqrt(M_PI / 2.0) * _A * _w * (1.0 + erf(t));
+    }
+    double RingGeometry::SigmaZ() const
+    {
+        double t = _R0 / (M_SQRT2 * _w);
+        return 2.0 * _A * _hz * exp(-t * t);
+    }
+    Vec3 RingGeometry::generatePosition(Random& random) const
+    {
+        // Random::cdfLinLin (Random.cpp:190-195) on the tabulated radial distribution, then phi, then z
+        double X = random.uniform();
+        int i = nr::locateClip(_Xv, X);
+        double R = nr::interpolateLinLin(X, _Xv[i], _Xv[i + 1], _Rv[i], _Rv[i + 1]);
+        double phi = 2.0 * M_PI * random.uniform();
+        X = random.uniform();
+        double z = (X <= 0.5) ? _hz * log(2.0 * X) : -_hz * log(2.0 * (1.0 - X));
+        return Vec3{R * cos(phi), R * sin(phi), z};
+    }
+
     // ================================================================ DustMix (DustMix.cpp:47-162)
 
     void DustMix::setup(double rangeMin, double rangeMax, const std::vector<double>& simulationWavelengths)

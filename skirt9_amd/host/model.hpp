@@ -139,6 +139,60 @@ namespace skh
         double _c, _rho0;
     };
 
+    // ShellGeometry (ShellGeometry.cpp:12-58): power-law shell A r^-p between two radii
+    class ShellGeometry : public Geometry
+    {
+    public:
+        ShellGeometry(double rmin, double rmax, double p);
+        std::string type() const override { return "ShellGeometry"; }
+        double density(Vec3 r) const override;
+        double SigmaX() const override { return 2.0 * Sigmar(); }
+        double SigmaY() const override { return 2.0 * Sigmar(); }
+        double SigmaZ() const override { return 2.0 * Sigmar(); }
+        double Sigmar() const;
+        Vec3 generatePosition(Random& random) const override;  // SpheGeometry.cpp:25-32, ShellGeometry.cpp:38-51
+
+    private:
+        double _rmin, _rmax, _p, _smin, _sdiff, _tmin, _tmax, _A;
+    };
+
+    // TorusGeometry (TorusGeometry.cpp:12-108): A r^-p exp(-q |cos theta|) within the opening angle
+    class TorusGeometry : public Geometry
+    {
+    public:
+        TorusGeometry(double p, double q, double Delta, double rmin, double rmax, bool rani, double rcut);
+        std::string type() const override { return "TorusGeometry"; }
+        double density(Vec3 r) const override;
+        double SigmaX() const override { return 2.0 * SigmaR(); }
+        double SigmaY() const override { return 2.0 * SigmaR(); }
+        double SigmaZ() const override { return 0.0; }
+        double SigmaR() const;
+        Vec3 generatePosition(Random& random) const override;
+
+    private:
+        double _p, _q, _Delta, _rmin, _rmax;
+        bool _rani;
+        double _rcut, _sinDelta, _smin, _sdiff, _tmin, _tmax, _A;
+    };
+
+    // RingGeometry (RingGeometry.cpp:13-77): Gaussian ring with an exponential vertical profile
+    class RingGeometry : public Geometry
+    {
+    public:
+        RingGeometry(double R0, double w, double hz);
+        std::string type() const override { return "RingGeometry"; }
+        double density(Vec3 r) const override;
+        double SigmaX() const override { return 2.0 * SigmaR(); }
+        double SigmaY() const override { return 2.0 * SigmaR(); }
+        double SigmaZ() const override;
+        double SigmaR() const;
+        Vec3 generatePosition(Random& random) const override;  // SepAxGeometry.cpp:11-19, RingGeometry.cpp:50-61
+
+    private:
+        double _R0, _w, _hz, _A;
+        Array _Rv, _Xv;
+    };
+
     // ---------------------------------------------------------------- dust mix (tabulated mean properties)
 
     // DustMix tables for a TabulatedDustMix subclass (MeanListDustMix / MeanFileDustMix):

@@ -66,6 +66,17 @@ namespace skh
             if (e.name == "SersicGeometry")
                 return std::make_unique<SersicGeometry>(rd.quantity(e, "effectiveRadius", "length"), rd.number(e, "index", "1"));
             if (e.name == "PlummerGeometry") return std::make_unique<PlummerGeometry>(rd.quantity(e, "scaleLength", "length"));
+            if (e.name == "ShellGeometry")
+                return std::make_unique<ShellGeometry>(rd.quantity(e, "minRadius", "length"), rd.quantity(e, "maxRadius", "length"),
+                                                       rd.number(e, "exponent", "2"));
+            if (e.name == "TorusGeometry")
+                return std::make_unique<TorusGeometry>(rd.number(e, "exponent", "1"), rd.number(e, "index", "1"),
+                                                       rd.quantity(e, "openingAngle", "posangle"), rd.quantity(e, "minRadius", "length"),
+                                                       rd.quantity(e, "maxRadius", "length"), rd.boolean(e, "reshapeInnerRadius", false),
+                                                       rd.quantity(e, "cutoffRadius", "length", "0"));
+            if (e.name == "RingGeometry")
+                return std::make_unique<RingGeometry>(rd.quantity(e, "ringRadius", "length"), rd.quantity(e, "width", "length"),
+                                                      rd.quantity(e, "height", "length"));
             unsupported("geometry " + e.name);
         }
 

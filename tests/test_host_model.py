@@ -292,6 +292,21 @@ def test_voronoi_sites_from_the_dust_density():
     assert np.allclose(dens, gold["density"], rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("name", ["cfg2shell", "cfg2torus", "cfg2ring"])
+def test_more_medium_geometries_bit_exact(name):
+    """ShellGeometry, TorusGeometry and RingGeometry as the dust distribution (density, column density for the optical
+    depth normalisation): the octree built by DensityTreePolicy has the reference's cells, and every cell the
+    reference's volume and sampled density, bit for bit"""
+    sim = Simulation(ski(name + ".ski")).setup()
+    gold = np.load(golden(name + "_cells.npz"))
+    head = scene_head(sim)
+    n = head.grid.num_cells
+    assert head.grid.kind == 2 and n == len(gold["density"])
+    dens = np.ctypeslib.as_array(head.medium.number_density, shape=(n,))
+    assert np.count_nonzero(dens) > n // 10
+    assert np.array_equal(dens.view(np.uint64), gold["density"].view(np.uint64))
+
+
 # ---------------------------------------------------------------- tabulated source spectra
 
 class SourceHead(C.Structure):
