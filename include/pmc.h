@@ -137,7 +137,9 @@ typedef struct pmc_source
     double  box[6];                 /* uniform box source: xmin,ymin,zmin,xmax,ymax,zmax;
                                        exponential disk (ExpDiskGeometry.cpp:46-68, SepAxGeometry.cpp:11-19): scale length,
                                        scale height, min radius, max radius (0: none), max |z| (0: none);
-                                       Plummer sphere (PlummerGeometry.cpp:29-33): scale length */
+                                       Plummer sphere (PlummerGeometry.cpp:29-33): scale length;
+                                       Sersic and Plummer: box[5] = flattening q of a SpheroidalGeometryDecorator
+                                       (SpheroidalGeometryDecorator.cpp:19-25: z -> q z; 0: none) */
 
     double  packet_luminosity;      /* L/Npp * Lv[h]/Wv[h]  (SourceSystem.cpp:96,105-106), before the lambda weight */
 

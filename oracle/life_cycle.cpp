@@ -793,6 +793,8 @@ namespace
                 r = V3{s.box[0] + x * (s.box[3] - s.box[0]), s.box[1] + y * (s.box[4] - s.box[1]),
                        s.box[2] + z * (s.box[5] - s.box[2])};
             }
+            // SpheroidalGeometryDecorator::generatePosition (SpheroidalGeometryDecorator.cpp:19-25)
+            if ((s.kind == PMC_SOURCE_SERSIC || s.kind == PMC_SOURCE_PLUMMER) && s.box[5] != 0.) r.z = s.box[5] * r.z;
             V3 k = randomDirection(rng);
             double Lw = L * w;
             pp.lambda = lambda;

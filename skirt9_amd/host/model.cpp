@@ -279,6 +279,22 @@ namespace skh
         return Vec3{r * k.x, r * k.y, r * k.z};
     }
 
+    // ================================================================ SpheroidalGeometryDecorator
+
+    double SpheroidalGeometry::density(Vec3 bfr) const
+    {
+        // AxGeometry::density(Position) passes (cylindrical radius, height); the spherical density is evaluated at radius
+        // m (a position (m, 0, 0): sqrt(m*m) == m in IEEE arithmetic)
+        double R = sqrt(bfr.x * bfr.x + bfr.y * bfr.y), z = bfr.z;
+        double m = sqrt(R * R + z * z / (_q * _q));
+        return 1.0 / _q * _inner->density(Vec3{m, 0., 0.});
+    }
+    Vec3 SpheroidalGeometry::generatePosition(Random& random) const
+    {
+        Vec3 s = _inner->generatePosition(random);
+        return Vec3{s.x, s.y, _q * s.z};
+    }
+
     // ================================================================ ShellGeometry, TorusGeometry, RingGeometry
 
     namespace

@@ -139,6 +139,26 @@ namespace skh
         double _c, _rho0;
     };
 
+    // SpheroidalGeometryDecorator (SpheroidalGeometryDecorator.cpp:11-43): a spherical geometry flattened along z by q
+    class SpheroidalGeometry : public Geometry
+    {
+    public:
+        SpheroidalGeometry(std::unique_ptr<Geometry> spherical, double q) : _inner(std::move(spherical)), _q(q) {}
+        std::string type() const override { return "SpheroidalGeometryDecorator"; }
+        double density(Vec3 r) const override;
+        double SigmaX() const override { return 2.0 * SigmaR(); }
+        double SigmaY() const override { return 2.0 * SigmaR(); }
+        double SigmaZ() const override { return 2.0 * (_inner->SigmaX() / 2.0); }
+        double SigmaR() const { return 1.0 / _q * (_inner->SigmaX() / 2.0); }
+        Vec3 generatePosition(Random& random) const override;
+        const Geometry* inner() const { return _inner.get(); }
+        double flattening() const { return _q; }
+
+    private:
+        std::unique_ptr<Geometry> _inner;
+        double _q;
+    };
+
     // ShellGeometry (ShellGeometry.cpp:12-58): power-law shell A r^-p between two radii
     class ShellGeometry : public Geometry
     {

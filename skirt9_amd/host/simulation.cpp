@@ -66,6 +66,14 @@ namespace skh
             if (e.name == "SersicGeometry")
                 return std::make_unique<SersicGeometry>(rd.quantity(e, "effectiveRadius", "length"), rd.number(e, "index", "1"));
             if (e.name == "PlummerGeometry") return std::make_unique<PlummerGeometry>(rd.quantity(e, "scaleLength", "length"));
+            if (e.name == "SpheroidalGeometryDecorator")
+            {
+                const XmlElement* inner = e.item("geometry");
+                if (!inner) throw std::runtime_error("ski: SpheroidalGeometryDecorator lacks a geometry");
+                if (inner->name != "SersicGeometry" && inner->name != "PlummerGeometry" && inner->name != "ShellGeometry")
+                    unsupported("SpheroidalGeometryDecorator of " + inner->name);
+                return std::make_unique<SpheroidalGeometry>(makeGeometry(*inner, rd), rd.number(e, "flattening", "1"));
+            }
             if (e.name == "ShellGeometry")
                 return std::make_unique<ShellGeometry>(rd.quantity(e, "minRadius", "length"), rd.quantity(e, "maxRadius", "length"),
                                                        rd.number(e, "exponent", "2"));
@@ -224,9 +232,13 @@ namespace skh
         {
             const XmlElement* g = src.item("geometry");
             if (!g) throw std::runtime_error("ski: GeometricSource lacks a geometry");
-            if (g->name != "SersicGeometry" && g->name != "UniformBoxGeometry" && g->name != "ExpDiskGeometry" && g->name != "PlummerGeometry")
+            if (g->name != "SersicGeometry" && g->name != "UniformBoxGeometry" && g->name != "ExpDiskGeometry" && g->name != "PlummerGeometry"
+                && g->name != "SpheroidalGeometryDecorator")
                 unsupported("source geometry " + g->name);
             _source.geometry = makeGeometry(*g, rd);
+            if (auto sph = dynamic_cast<SpheroidalGeometry*>(_source.geometry.get()))
+                if (sph->inner()->type() != "SersicGeometry" && sph->inner()->type() != "PlummerGeometry")
+                    unsupported("source geometry SpheroidalGeometryDecorator of " + sph->inner()->type());
             if (src.item("velocityDistribution") && rd.quantity(src, "velocityMagnitude", "velocity", "0") && !_oligo)
                 unsupported("a source with a velocity field");
         }
@@ -845,7 +857,15 @@ namespace skh
             s.position[1] = _source.position.y;
             s.position[2] = _source.position.z;
         }
-        else if (auto sersic = dynamic_cast<SersicGeometry*>(_source.geometry.get()))
+        const Geometry* shape = _source.geometry.get();
+        double flattening = 0.;
+        if (auto sph = dynamic_cast<const SpheroidalGeometry*>(shape))
+        {
+            shape = sph->inner();
+            flattening = sph->flattening();
+        }
+        if (_source.type == "PointSource") {}
+        else if (auto sersic = dynamic_cast<const SersicGeometry*>(shape))
         {
             s.kind = PMC_SOURCE_SERSIC;
             s.reff = sersic->reff();
@@ -853,23 +873,24 @@ namespace skh
             s.sersic_s = sersic->function().sv().data();
             s.sersic_M = sersic->function().Mv().data();
         }
-        else if (auto ubox = dynamic_cast<UniformBoxGeometry*>(_source.geometry.get()))
+        else if (auto ubox = dynamic_cast<const UniformBoxGeometry*>(shape))
         {
             s.kind = PMC_SOURCE_UNIFORM_BOX;
             const Box& b = ubox->box();
             double v[6] = {b.xmin, b.ymin, b.zmin, b.xmax, b.ymax, b.zmax};
             std::memcpy(s.box, v, sizeof(v));
         }
-        else if (auto disk = dynamic_cast<ExpDiskGeometry*>(_source.geometry.get()))
+        else if (auto disk = dynamic_cast<const ExpDiskGeometry*>(shape))
         {
             s.kind = PMC_SOURCE_EXP_DISK;
             disk->parameters(s.box);
         }
-        else if (auto plummer = dynamic_cast<PlummerGeometry*>(_source.geometry.get()))
+        else if (auto plummer = dynamic_cast<const PlummerGeometry*>(shape))
         {
             s.kind = PMC_SOURCE_PLUMMER;
             s.box[0] = plummer->scaleLength();
         }
+        if (flattening) s.box[5] = flattening;  // SpheroidalGeometryDecorator of a Sersic or Plummer source: z -> q z
     }
 
     void Simulation::buildScene()
