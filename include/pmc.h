@@ -129,7 +129,8 @@ enum { PMC_SED_TABULATED = 0, PMC_SED_BLACKBODY = 1 };
 typedef struct pmc_source
 {
     int32_t kind;                   /* PMC_SOURCE_* (single source; SourceSystem with Ns = 1) */
-    double  position[3];            /* point source position */
+    double  position[3];            /* point source position; geometric sources: offset added to the sampled position
+                                       (OffsetGeometryDecorator.cpp:33-39; zeros: none) */
     double  reff;                   /* Sersic: effective radius; tables of SersicFunction (SersicFunction.cpp:13-77) */
     int32_t sersic_n;               /*   number of table points (101) */
     const double* sersic_s;         /*   _sv */

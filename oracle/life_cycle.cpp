@@ -795,6 +795,9 @@ namespace
             }
             // SpheroidalGeometryDecorator::generatePosition (SpheroidalGeometryDecorator.cpp:19-25)
             if ((s.kind == PMC_SOURCE_SERSIC || s.kind == PMC_SOURCE_PLUMMER) && s.box[5] != 0.) r.z = s.box[5] * r.z;
+            // OffsetGeometryDecorator::generatePosition (OffsetGeometryDecorator.cpp:33-39)
+            if (s.kind != PMC_SOURCE_POINT && (s.position[0] != 0. || s.position[1] != 0. || s.position[2] != 0.))
+                r = V3{r.x + s.position[0], r.y + s.position[1], r.z + s.position[2]};
             V3 k = randomDirection(rng);
             double Lw = L * w;
             pp.lambda = lambda;

@@ -159,6 +159,29 @@ namespace skh
         double _q;
     };
 
+    // OffsetGeometryDecorator (OffsetGeometryDecorator.cpp:18-52): any geometry shifted by a fixed vector
+    class OffsetGeometry : public Geometry
+    {
+    public:
+        OffsetGeometry(std::unique_ptr<Geometry> geometry, Vec3 offset) : _inner(std::move(geometry)), _offset(offset) {}
+        std::string type() const override { return "OffsetGeometryDecorator"; }
+        double density(Vec3 r) const override { return _inner->density(Vec3{r.x - _offset.x, r.y - _offset.y, r.z - _offset.z}); }
+        double SigmaX() const override { return _inner->SigmaX(); }
+        double SigmaY() const override { return _inner->SigmaY(); }
+        double SigmaZ() const override { return _inner->SigmaZ(); }
+        Vec3 generatePosition(Random& random) const override
+        {
+            Vec3 r = _inner->generatePosition(random);
+            return Vec3{r.x + _offset.x, r.y + _offset.y, r.z + _offset.z};
+        }
+        const Geometry* inner() const { return _inner.get(); }
+        Vec3 offset() const { return _offset; }
+
+    private:
+        std::unique_ptr<Geometry> _inner;
+        Vec3 _offset;
+    };
+
     // ShellGeometry (ShellGeometry.cpp:12-58): power-law shell A r^-p between two radii
     class ShellGeometry : public Geometry
     {

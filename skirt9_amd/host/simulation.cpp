@@ -66,6 +66,14 @@ namespace skh
             if (e.name == "SersicGeometry")
                 return std::make_unique<SersicGeometry>(rd.quantity(e, "effectiveRadius", "length"), rd.number(e, "index", "1"));
             if (e.name == "PlummerGeometry") return std::make_unique<PlummerGeometry>(rd.quantity(e, "scaleLength", "length"));
+            if (e.name == "OffsetGeometryDecorator")
+            {
+                const XmlElement* inner = e.item("geometry");
+                if (!inner) throw std::runtime_error("ski: OffsetGeometryDecorator lacks a geometry");
+                return std::make_unique<OffsetGeometry>(makeGeometry(*inner, rd),
+                                                        Vec3{rd.quantity(e, "offsetX", "length", "0"), rd.quantity(e, "offsetY", "length", "0"),
+                                                             rd.quantity(e, "offsetZ", "length", "0")});
+            }
             if (e.name == "SpheroidalGeometryDecorator")
             {
                 const XmlElement* inner = e.item("geometry");
@@ -233,10 +241,16 @@ namespace skh
             const XmlElement* g = src.item("geometry");
             if (!g) throw std::runtime_error("ski: GeometricSource lacks a geometry");
             if (g->name != "SersicGeometry" && g->name != "UniformBoxGeometry" && g->name != "ExpDiskGeometry" && g->name != "PlummerGeometry"
-                && g->name != "SpheroidalGeometryDecorator")
+                && g->name != "SpheroidalGeometryDecorator" && g->name != "OffsetGeometryDecorator")
                 unsupported("source geometry " + g->name);
             _source.geometry = makeGeometry(*g, rd);
-            if (auto sph = dynamic_cast<SpheroidalGeometry*>(_source.geometry.get()))
+            const Geometry* undecorated = _source.geometry.get();
+            if (auto off = dynamic_cast<const OffsetGeometry*>(undecorated)) undecorated = off->inner();
+            const std::string ut = undecorated->type();
+            if (ut != "SersicGeometry" && ut != "UniformBoxGeometry" && ut != "ExpDiskGeometry" && ut != "PlummerGeometry"
+                && ut != "SpheroidalGeometryDecorator")
+                unsupported("source geometry " + ut);
+            if (auto sph = dynamic_cast<const SpheroidalGeometry*>(undecorated))
                 if (sph->inner()->type() != "SersicGeometry" && sph->inner()->type() != "PlummerGeometry")
                     unsupported("source geometry SpheroidalGeometryDecorator of " + sph->inner()->type());
             if (src.item("velocityDistribution") && rd.quantity(src, "velocityMagnitude", "velocity", "0") && !_oligo)
@@ -858,6 +872,12 @@ namespace skh
             s.position[2] = _source.position.z;
         }
         const Geometry* shape = _source.geometry.get();
+        if (auto off = dynamic_cast<const OffsetGeometry*>(shape))
+        {
+            // OffsetGeometryDecorator::generatePosition: the offset travels in the position member
+            shape = off->inner();
+            s.position[0] = off->offset().x, s.position[1] = off->offset().y, s.position[2] = off->offset().z;
+        }
         double flattening = 0.;
         if (auto sph = dynamic_cast<const SpheroidalGeometry*>(shape))
         {
