@@ -548,6 +548,12 @@ namespace skh
         // CartesianSpatialGrid.cpp:22-24
         auto meshOf = [](const MeshSpec& spec, int n) {
             Array tv;
+            if (spec.type == "ListMesh")
+            {
+                tv.resize(spec.points.size());
+                for (size_t i = 0; i < spec.points.size(); ++i) tv[i] = spec.points[i];
+                return tv;
+            }
             if (spec.type == "PowMesh" && n > 1)
             {
                 // NR::buildPowerLawGrid

@@ -401,6 +401,7 @@ namespace skh
             std::string type{"LinMesh"};
             double ratio{1};                  // PowMesh, SymPowMesh: last/first resp. outermost/innermost bin width
             double centralBinFraction{1e-3};  // LogMesh, SymLogMesh
+            std::vector<double> points;       // ListMesh: the normalised border points (TabulatedMesh.cpp:12-33)
         };
         MeshSpec meshSpec[3];
         Array xv, yv, zv;

@@ -467,6 +467,27 @@ namespace skh
                 CartesianSpatialGrid::MeshSpec& spec = grid->meshSpec[axisIndex++];
                 const XmlElement* mesh = ge->item(prop);
                 if (!mesh) return 100;  // Mesh default numBins
+                if (mesh->name == "ListMesh")
+                {
+                    // TabulatedMesh::setupSelfBefore (TabulatedMesh.cpp:12-33) on ListMesh::getMeshBorderPoints
+                    std::vector<double> points;
+                    std::string text = mesh->attr("points", "");
+                    for (char& ch : text)
+                        if (ch == ',') ch = ' ';
+                    std::istringstream in(text);
+                    for (double v; in >> v;) points.push_back(v);
+                    std::sort(points.begin(), points.end());
+                    points.erase(std::unique(points.begin(), points.end()), points.end());
+                    if (points.size() < 1) throw std::runtime_error("The mesh data file has no points");
+                    if (points.front() < 0.) throw std::runtime_error("The mesh data file has negative points");
+                    if (points.front() != 0.) points.insert(points.begin(), 0.);
+                    if (points.size() < 2 || points.back() == 0.) throw std::runtime_error("The mesh data file has no positive points");
+                    const double last = points.back();
+                    for (double& v : points) v /= last;
+                    spec.type = mesh->name;
+                    spec.points = points;
+                    return static_cast<int>(points.size()) - 1;
+                }
                 if (mesh->name != "LinMesh" && mesh->name != "PowMesh" && mesh->name != "SymPowMesh" && mesh->name != "LogMesh"
                     && mesh->name != "SymLogMesh")
                     unsupported("mesh " + mesh->name);

@@ -307,6 +307,21 @@ def test_more_medium_geometries_bit_exact(name):
     assert np.array_equal(dens.view(np.uint64), gold["density"].view(np.uint64))
 
 
+def test_list_mesh_bit_exact():
+    """ListMesh (TabulatedMesh.cpp:12-33: sorted unique points, zero inserted, scaled by the last point) along z of a
+    Cartesian grid: the reference's cell volumes and sampled densities, bit for bit"""
+    sim = Simulation(ski("cfg1list.ski")).setup()
+    gold = np.load(golden("cfg1list_cells.npz"))
+    head = scene_head(sim)
+    n = head.grid.num_cells
+    assert head.grid.kind == 1 and n == 30 * 25 * 10 == len(gold["density"])
+    zv = np.ctypeslib.as_array(head.grid.zv, shape=(11,))
+    vol = gold["volume"].reshape(30, 25, 10)
+    assert np.allclose(np.diff(zv) / np.diff(zv)[0], vol[0, 0, :] / vol[0, 0, 0], rtol=1e-12)
+    dens = np.ctypeslib.as_array(head.medium.number_density, shape=(n,))
+    assert np.array_equal(dens.view(np.uint64), gold["density"].view(np.uint64))
+
+
 # ---------------------------------------------------------------- tabulated source spectra
 
 class SourceHead(C.Structure):
