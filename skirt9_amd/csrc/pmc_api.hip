@@ -141,6 +141,11 @@ namespace
         uint32_t rootLink{0};
         int coarseLevel{0};
         std::vector<uint32_t> coarse;    // [2^Lc]^3 (z, y, x): link of the covering node at level <= Lc
+        // device numbering of the cells: dev = perm[m]; groups of 2^g consecutive cells (siblings: one sector of the
+        // per-axis table) stay together, the groups are scattered over the table so that the cells of a hot region do
+        // not share L2 channels; cellExt[dev] = m (or -1 for padding); cellSlots = entries per device table
+        std::vector<int32_t> perm, cellExt;
+        int cellSlots{0};
     };
 
     int buildTree(const pmc_grid& g, const double* density, TreeBuild& T)
@@ -208,6 +213,36 @@ namespace
                     if (std::isnan(mid))
                         mid = (T.table[size_t(axis) * T.tabn + lo] + T.table[size_t(axis) * T.tabn + lo + size]) / 2.;
                 }
+        // device numbering of the cells (identity unless PMC_CELL_SHUFFLE=g asks for groups of 2^g cells to be scattered)
+        {
+            const int n = g.num_cells;
+            int gb = -1;
+            if (const char* env = getenv("PMC_CELL_SHUFFLE")) gb = atoi(env);
+            T.perm.resize(n);
+            if (gb < 0 || gb > 16)
+            {
+                T.cellSlots = n;
+                for (int m = 0; m < n; ++m) T.perm[m] = m;
+            }
+            else
+            {
+                const int groupSize = 1 << gb;
+                const int numGroups = (n + groupSize - 1) / groupSize;
+                std::vector<int32_t> where(numGroups);
+                for (int i = 0; i < numGroups; ++i) where[i] = i;
+                uint64_t state = 0x9E3779B97F4A7C15ull;  // fixed: the numbering is a pure function of the scene
+                for (int i = numGroups - 1; i > 0; --i)
+                {
+                    state = state * 6364136223846793005ull + 1442695040888963407ull;
+                    const int j = int((state >> 33) % uint64_t(i + 1));
+                    std::swap(where[i], where[j]);
+                }
+                T.cellSlots = numGroups * groupSize;
+                for (int m = 0; m < n; ++m) T.perm[m] = where[m >> gb] * groupSize + (m & (groupSize - 1));
+            }
+            T.cellExt.assign(T.cellSlots, -1);
+            for (int m = 0; m < n; ++m) T.cellExt[T.perm[m]] = m;
+        }
         // box code (pmc_device.h LeafRec::code): LDS byte offsets of the three lower wall entries + size exponent
         auto code = [&](int id) -> uint64_t {
             const uint64_t ox = 8ull * uint64_t(fx[id]);
@@ -219,7 +254,7 @@ namespace
         auto linkOf = [&](int id) -> uint32_t {
             if (id < 0) return PMC_LINK_NONE;
             const uint32_t e = uint32_t(maxLevel - g.node_level[id]);
-            return g.node_first_child[id] < 0 ? (e | (uint32_t(g.node_cell[id]) << 4))
+            return g.node_first_child[id] < 0 ? (e | (uint32_t(T.perm[g.node_cell[id]]) << 4))
                                               : (e | (uint32_t(internalIndex[id]) << 4) | PMC_LINK_NODE);
         };
         T.rootLink = linkOf(0);
@@ -267,10 +302,11 @@ namespace
         };
 
         const int numCells = g.num_cells;
-        T.leaves.assign(numCells, LeafRec{});
-        T.axis.assign(3 * size_t(numCells), AxisRec{});
+        const int cellSlots = T.cellSlots;
+        T.leaves.assign(cellSlots, LeafRec{});
+        T.axis.assign(3 * size_t(cellSlots), AxisRec{});
         T.internals.assign(numInternal, NodeRec{});
-        T.nbrStart.assign(6 * size_t(numCells) + 1, 0);
+        T.nbrStart.assign(6 * size_t(cellSlots) + 1, 0);
         T.nbrList.clear();
         std::vector<int32_t> nodeOfCell(numCells, -1);
         for (int id = 0; id < numNodes; ++id)
@@ -289,10 +325,14 @@ namespace
             }
         }
         for (int m = 0; m < numCells; ++m)
+            if (nodeOfCell[m] < 0) return fail(PMC_ERR_INVALID, "cell without a leaf node");
+        for (int dev = 0; dev < cellSlots; ++dev)
         {
-            int id = nodeOfCell[m];
-            if (id < 0) return fail(PMC_ERR_INVALID, "cell without a leaf node");
-            LeafRec& rec = T.leaves[m];
+            const int m = T.cellExt[dev];
+            for (int wall = 0; wall < 6; ++wall) T.nbrStart[6 * size_t(dev) + wall] = (int32_t)T.nbrList.size();
+            if (m < 0) continue;  // padding of the last group
+            const int id = nodeOfCell[m];
+            LeafRec& rec = T.leaves[dev];
             rec.code = code(id);
             rec.density = density[m];
             for (int wall = 0; wall < 6; ++wall)
@@ -300,21 +340,21 @@ namespace
                 const int axis = wall >> 1, side = wall & 1;
                 // the leaf across the wall (same size or coarser), or the same-size internal node (finer neighbours: the walk
                 // descends from it by the index bits of its position), or "outside"
-                AxisRec& hot = T.axis[size_t(axis) * numCells + m];
+                AxisRec& hot = T.axis[size_t(axis) * cellSlots + dev];
                 hot.density = density[m];
                 hot.link[side] = linkOf(covering(id, wall));
-                // the reference's neighbour list of this leaf, re-indexed by cell
-                T.nbrStart[6 * size_t(m) + wall] = (int32_t)T.nbrList.size();
+                // the reference's neighbour list of this leaf, in device numbering
+                T.nbrStart[6 * size_t(dev) + wall] = (int32_t)T.nbrList.size();
                 for (int qq = g.nbr_start[6 * size_t(id) + wall]; qq < g.nbr_start[6 * size_t(id) + wall + 1]; ++qq)
                 {
                     int nb = g.nbr_list[qq];
                     if (g.node_first_child[nb] >= 0)
                         return fail(PMC_ERR_INVALID, "neighbour list of a leaf contains a non-leaf node");
-                    T.nbrList.push_back(g.node_cell[nb]);
+                    T.nbrList.push_back(T.perm[g.node_cell[nb]]);
                 }
             }
         }
-        T.nbrStart[6 * size_t(numCells)] = (int32_t)T.nbrList.size();
+        T.nbrStart[6 * size_t(cellSlots)] = (int32_t)T.nbrList.size();
         return PMC_OK;
     }
 
@@ -534,6 +574,8 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if ((rc = ctx->upload(T.coarse.data(), T.coarse.size(), &D.coarse_tab))) return bail(rc);
         if ((rc = ctx->upload(T.nbrStart.data(), T.nbrStart.size(), &D.nbr_start))) return bail(rc);
         if ((rc = ctx->upload(T.nbrList.data(), T.nbrList.size(), &D.nbr_list))) return bail(rc);
+        if ((rc = ctx->upload(T.cellExt.data(), T.cellExt.size(), &D.cell_ext))) return bail(rc);
+        D.cell_slots = T.cellSlots;
         D.lds_grid_len = 3 * T.tabn;
     }
 

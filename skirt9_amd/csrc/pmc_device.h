@@ -186,6 +186,10 @@ struct DevScene
     const int32_t* nbr_start;    // [6*num_cells + 1]
     const int32_t* nbr_list;     // leaf cell indices
     int32_t num_cells;
+    // octree: the device tables number the cells in their own order (pmc_api.hip buildTree: sibling groups scattered
+    // over the table); cell_ext[device index] = the caller's cell index m, cell_slots = entries per device table
+    const int32_t* cell_ext;
+    int32_t cell_slots;
     // Voronoi (pmc_grid::site ...): site positions as double4-aligned records {x, y, z, number density}, so that one
     // 32-byte gather brings everything the traversal needs of a neighbour or of the cell itself
     const double* vsite;          // [num_cells][4]

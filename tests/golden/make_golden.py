@@ -21,6 +21,10 @@ Fixtures:
                for bit, cell volumes to rounding, sampled densities and output files statistically)
   cfg5_rays*   config 5 at full size (tests/ski/cfg5.ski, 10^5 Voronoi sites from tools/make_sites.py): 208 fixed rays and
                the reference's (m, ds) sequences
+  cfg2_rays*, cfg2_cells.json   BASELINE configs[1] at FULL size (tests/ski/cfg2.ski: the 953 688-cell octree of the headline
+               benchmark): 312 fixed rays (random, mid-plane, axis-parallel, and rays aimed at cell corners and edges) with the
+               reference's (m, ds) sequences (gzip), the cell count and SHA-256 digests of the reference's per-cell volumes and
+               number densities (bit patterns, cell order)
   cfg5dd_cells.npz   the same grid with its sites drawn from the dust density (policy DustDensity): volumes, densities
   cfg4small_*  reduced config 4 (tests/ski/cfg4small.ski): dust imported from 3000 smoothed particles
                (tests/ski/cfg4small_sph.txt, made by tools/make_sph.py), 2x10^4 packets -> files, rays, cells
@@ -54,6 +58,39 @@ def rays(scale, n, seed):
             (np.zeros(3), np.array([s2, s2, 0])), (np.array([scale * 0.25, scale * 0.125, 0.0]), np.array([0, 0, -1.0])),
             (np.array([-scale * 2, 0.0, 0.0]), np.array([1.0, 0, 0])), (np.array([-scale * 2, 1.0, 1.0]), np.array([-1.0, 0, 0])),
             (np.array([1e15, 2e15, -3e15]), np.array([0.3, 0.5, 0.81]) / np.linalg.norm([0.3, 0.5, 0.81]))]
+    return out
+
+
+def rays_config2():
+    """fixed rays for the full-size octree of tests/ski/cfg2.ski (box +-20 kpc x +-20 kpc x +-4 kpc): random rays, rays
+    nearly in the mid-plane (hundreds of cells of the finest levels), the special rays of rays(), and rays through the
+    corners and edges of cells (ties between exit walls, steps that overshoot a second wall)"""
+    pc = 3.08567758e16
+    scale = 4000 * pc
+    rng = np.random.default_rng(7)
+    out = []
+    for i in range(280):
+        r = (rng.random(3) - 0.5) * 2 * scale * np.array([5.0, 5.0, 1.0]) * (1.2 if i % 5 == 0 else 0.95)
+        k = rng.normal(size=3)
+        if i % 3 == 0:
+            k[2] *= 0.02
+        k /= np.linalg.norm(k)
+        out.append((r, k))
+    out += rays(scale, 0, 1)
+    # dyadic points of the box are node corners: (i/2^a) of the extent; rays through them along diagonals
+    ext = np.array([20000 * pc, 20000 * pc, 4000 * pc])
+    s2, s3 = 1 / np.sqrt(2.0), 1 / np.sqrt(3.0)
+    for frac, k in (((0.0, 0.0, 0.0), (s3, s3, s3)), ((0.25, 0.125, 0.0), (s2, -s2, 0.0)), ((0.03125, -0.0625, 0.015625), (s3, -s3, s3)),
+                    ((-0.5, 0.25, 0.0), (0.0, s2, s2)), ((0.0078125, 0.0078125, 0.0), (1.0, 0.0, 0.0)),
+                    ((0.001953125, -0.00390625, 0.0009765625), (-s3, s3, s3)), ((0.0, 0.0, 0.001953125), (s2, s2, 0.0)),
+                    ((0.5, 0.5, 0.5), (-s3, -s3, -s3)), ((-1.5, -1.5, -1.5), (s3, s3, s3)), ((0.0625, 0.0, 0.0), (0.0, 0.0, 1.0)),
+                    ((0.0, 0.03125, 0.0), (0.6, 0.0, 0.8)), ((0.015625, 0.015625, 0.015625), (0.0, -0.6, 0.8)),
+                    ((0.125, 0.125, 0.0), (-s2, -s2, 0.0)), ((0.0, 0.0, 0.0), (s2, 0.0, s2)), ((0.0009765625, 0.0, 0.0), (0.0, 1.0, 0.0)),
+                    ((-0.25, -0.25, -0.25), (s3, s3, s3)), ((0.0, 0.0, 0.0), (-s3, s3, -s3)), ((0.75, -0.75, 0.0), (-s2, s2, 0.0)),
+                    ((0.00390625, 0.00390625, 0.00390625), (s3, s3, -s3)), ((0.0, -0.001953125, 0.0), (s2, s2, 0.0)),
+                    ((0.25, 0.0, 0.0625), (-0.8, 0.0, -0.6)), ((0.0, 0.0, -0.03125), (0.0, s2, s2)),
+                    ((0.0625, 0.0625, 0.0), (s2, s2, 0.0)), ((0.0, 0.0, 0.0), (0.0, s2, -s2))):
+        out.append((np.array(frac) * ext, np.array(k) / np.linalg.norm(k)))
     return out
 
 
@@ -137,6 +174,35 @@ def main():
                     fh.write(" ".join(float(v).hex() for v in list(r) + list(k)) + "\n")
             subprocess.check_call([REF, "rays", os.path.join(ROOT, "tests", "ski", "cfg5.ski"), rayfile,
                                    os.path.join(HERE, "cfg5_rays_ref.txt"), "-o", tmp], cwd=tmp, stdout=subprocess.DEVNULL)
+    # config 2 at full size: the traversal and the cell table of the benchmark's own octree
+    if len(sys.argv) == 1 or "cfg2" in sys.argv[1:]:
+        import gzip
+        import hashlib
+        import json
+        ski = os.path.join(ROOT, "tests", "ski", "cfg2.ski")
+        with tempfile.TemporaryDirectory() as tmp:
+            rayfile = os.path.join(HERE, "cfg2_rays.txt")
+            with open(rayfile, "w") as fh:
+                for r, k in rays_config2():
+                    fh.write(" ".join(float(v).hex() for v in list(r) + list(k)) + "\n")
+            ref = os.path.join(tmp, "cfg2_rays_ref.txt")
+            subprocess.check_call([REF, "rays", ski, rayfile, ref, "-o", tmp], cwd=tmp, stdout=subprocess.DEVNULL)
+            with open(ref, "rb") as src, gzip.GzipFile(os.path.join(HERE, "cfg2_rays_ref.txt.gz"), "wb", mtime=0) as dst:
+                dst.write(src.read())
+            cells = os.path.join(tmp, "cells.txt")
+            subprocess.check_call([REF, "cells", ski, cells, "-w", "0.55e-6", "-o", tmp], cwd=tmp, stdout=subprocess.DEVNULL)
+            vol, dens = [], []
+            for line in open(cells):
+                t = line.split()
+                if t[0] in ("cells", "mix"):
+                    continue
+                vol.append(float.fromhex(t[4]))
+                dens.append(float.fromhex(t[5]))
+            vol, dens = np.array(vol), np.array(dens)
+            json.dump({"num_cells": int(len(dens)), "volume_sha256": hashlib.sha256(vol.tobytes()).hexdigest(),
+                       "density_sha256": hashlib.sha256(dens.tobytes()).hexdigest(),
+                       "density_sum": float(dens.sum()).hex(), "volume_sum": float(vol.sum()).hex()},
+                      open(os.path.join(HERE, "cfg2_cells.json"), "w"), indent=1)
     print("golden fixtures regenerated")
 
 

@@ -48,6 +48,21 @@ def test_full_octree_rays_bit_exact(full):
     assert total > 5000
 
 
+def test_full_octree_rays_equal_the_reference(full):
+    """the same octree against the UNMODIFIED reference: 312 fixed rays (tests/golden/cfg2_rays.txt: random, mid-plane,
+    axis-parallel, and rays through cell corners and edges) whose (m, ds) sequences the reference dumped
+    (tests/golden/make_golden.py cfg2, TreeSpatialGrid.cpp:132-217) -- bit for bit from the HIP traversal"""
+    from test_oracle_golden import _ray_fixture
+    sim, eng = full
+    total = 0
+    for r, k, m_ref, ds_ref in _ray_fixture("cfg2"):
+        m_gpu, ds_gpu = eng.trace_ray(r, k)
+        assert np.array_equal(m_ref, m_gpu), (r, k)
+        assert np.array_equal(ds_ref.view(np.uint64), ds_gpu.view(np.uint64)), (r, k)
+        total += len(m_ref)
+    assert total > 10000
+
+
 def test_full_size_conservation_and_linearity(full):
     sim, eng = full
     lay = sim.layout(0)

@@ -164,7 +164,11 @@ def _densities(sim):
 
 def _ray_fixture(name):
     rays = [[float.fromhex(t) for t in line.split()] for line in open(golden(name + "_rays.txt"))]
-    ref = open(golden(name + "_rays_ref.txt")).read().split("\n")
+    if os.path.exists(golden(name + "_rays_ref.txt.gz")):
+        import gzip
+        ref = gzip.open(golden(name + "_rays_ref.txt.gz"), "rt").read().split("\n")
+    else:
+        ref = open(golden(name + "_rays_ref.txt")).read().split("\n")
     out, pos = [], 0
     for i, ray in enumerate(rays):
         head = ref[pos].split()
@@ -194,6 +198,38 @@ def config5_simulation(tmp_dir, num_packets=1000):
             del os.environ["SKH_INPUT_PATH"]
         else:
             os.environ["SKH_INPUT_PATH"] = old
+
+
+def test_full_size_config2_equals_the_reference():
+    """BASELINE configs[1] at FULL size (tests/ski/cfg2.ski, the octree the benchmark runs on): the host layer builds the
+    reference's tree (953 688 cells; DensityTreePolicy.cpp:117-231, TreeSpatialGrid.cpp:34-130) with the reference's
+    volumes and sampled densities -- SHA-256 of the bit patterns in cell order -- and the oracle's path generator
+    reproduces the reference's (m, ds) sequences of 312 rays bit for bit, including rays through cell corners and edges
+    (TreeSpatialGrid.cpp:132-217)"""
+    import hashlib
+    import json
+    from test_host_model import scene_head
+    sim = Simulation(ski("cfg2.ski"), num_packets=1000).setup()
+    gold = json.load(open(golden("cfg2_cells.json")))
+    g = scene_head(sim).grid
+    assert g.num_cells == gold["num_cells"] == 953688
+    dens = _densities(sim)
+    assert hashlib.sha256(dens.tobytes()).hexdigest() == gold["density_sha256"]
+    n = g.num_nodes
+    box = np.ctypeslib.as_array(g.node_box, shape=(n, 6))
+    cell = np.ctypeslib.as_array(g.node_cell, shape=(n,))
+    leaf = np.ctypeslib.as_array(g.node_first_child, shape=(n,)) < 0
+    vol = ((box[:, 3] - box[:, 0]) * (box[:, 4] - box[:, 1]) * (box[:, 5] - box[:, 2]))[leaf][np.argsort(cell[leaf])]
+    assert hashlib.sha256(np.ascontiguousarray(vol).tobytes()).hexdigest() == gold["volume_sha256"]
+    total = 0
+    fixture = _ray_fixture("cfg2")
+    assert len(fixture) == 312
+    for r, k, m_ref, ds_ref in fixture:
+        m, ds = O.trace_ray(sim, r, k)
+        assert np.array_equal(m, m_ref), (r, k)
+        assert np.array_equal(ds.view(np.uint64), ds_ref.view(np.uint64)), (r, k)
+        total += len(m_ref)
+    assert total > 10000
 
 
 def test_full_size_voronoi_rays_bit_exact(tmp_path):

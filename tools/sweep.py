@@ -43,6 +43,7 @@ def main():
         eng.run_primary(0, P // 10, sim.seed)  # warm-up
         eng.sync()
         best = None
+        eng.reset_counters()
         for rep in range(2):
             eng.run_primary((rep + 1) * P, P, sim.seed)
             eng.sync()
@@ -51,6 +52,8 @@ def main():
                 best = t
         print(f"{v:60s} pkt/s {P / best['total_ms'] * 1e3:.3e} seg {best['total_ms']:.1f} walk {best['walk_ms']:.1f} "
               f"trans {best['transition_ms']:.1f} gen {best['generations']}  sum {frames.sum().item():.9e}", flush=True)
+        if os.environ.get("PMC_PROFILE_DUMP"):
+            eng.counters()  # a profiling build prints its in-kernel timers to stderr
         eng.close()
 
 
