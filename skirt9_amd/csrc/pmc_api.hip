@@ -17,27 +17,37 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 extern "C" hipError_t pmcUploadScene(int slot, const DevScene* scene, hipStream_t stream);
 extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds);
-extern "C" int pmcWalkBlocksPerCU(int gridKind, int block, size_t ldsBytes);
+extern "C" int pmcWalkBlocksPerCU(int gridKind, int kind, int wide, int block, size_t ldsBytes);
+extern "C" int pmcPeelBlock(void);
 extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int taskBase, int numTaskRecords, int taskCounter, uint64_t seed, int grid,
                                     int block, size_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, int cursor, int obs, int grid, size_t ldsBytes,
+                                    hipStream_t stream);
+extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, int cursor, uint64_t seed, int grid,
+                                    size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
                                           uint64_t seed, int maxBlocks, size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
                                       uint64_t first, uint64_t count, uint64_t seed, int initial, int grid, size_t ldsBytes,
                                       hipStream_t stream);
-extern "C" hipError_t pmcLaunchTrace(int slot, int gridKind, const double r[3], const double k[3], int32_t* m, double* ds,
-                                     int32_t cap, int32_t* n, size_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t pmcLaunchTrace(int slot, int gridKind, int wide, int uniform, const double r[3], const double k[3],
+                                     const double* kdev, int32_t* m, double* ds, int32_t cap, int32_t* n, size_t ldsBytes,
+                                     hipStream_t stream);
 
 namespace
 {
     thread_local std::string t_error;
-    // constant-memory scene slots (pmc_kernels.hip c_scene): one per live context
-    bool g_slotUsed[PMC_MAX_CONTEXTS] = {false};
+    // constant-memory scene slots (pmc_kernels.hip c_scene): every device has its own copy of the symbol, so the table
+    // of live contexts is per device; guarded, because contexts may be created from one host thread per GPU
+    constexpr int MAX_DEVICES = 64;
+    bool g_slotUsed[MAX_DEVICES][PMC_MAX_CONTEXTS] = {{false}};
+    std::mutex g_slotMutex;
 
     int fail(int code, const std::string& message)
     {
@@ -56,10 +66,6 @@ void pmcSetError(const std::string& message)
     t_error = message;
 }
 
-namespace
-{
-}
-
 #define HIP_TRY(call)                                           \
     do                                                          \
     {                                                           \
@@ -76,7 +82,9 @@ struct pmc_ctx
     // slot groups: the generations of group g are enqueued on groupStream[g] (group 0 uses `stream`)
     int numGroups{2};
     hipStream_t groupStream[PMC_MAX_GROUPS]{};
-    hipEvent_t evA[PMC_MAX_GROUPS]{}, evB[PMC_MAX_GROUPS]{}, evC[PMC_MAX_GROUPS]{};
+    // octree: the peel-off kernels of a generation run on a side stream of the group, next to its propagation kernel
+    hipStream_t peelStream[PMC_MAX_GROUPS]{};
+    hipEvent_t evA[PMC_MAX_GROUPS]{}, evB[PMC_MAX_GROUPS]{}, evC[PMC_MAX_GROUPS]{}, evJoin[PMC_MAX_GROUPS]{};
     hipEvent_t evStart{nullptr}, evStop{nullptr};
     bool timed{false};
     float totalMs{0}, walkMs{0}, transitionMs{0};
@@ -89,7 +97,9 @@ struct pmc_ctx
     int64_t rfSize{0};  // doubles of the radiation field table (0: not stored)
     size_t walkLds{0}, transitionLds{0};
     int block{256};
-    int grid{0};
+    int grid{0};          // workgroups of the generic walk kernel / the octree propagation kernel
+    int peelGrid{0};      // workgroups of an octree peel-off kernel
+    int wide{0};          // octree deeper than level 10: 21-bit index fields (pmc_walk_tree.inc Pack)
     int numCU{256};
     int64_t numSlots{0};         // requested pool size
     int64_t allocatedSlots{0};   // size of the allocated slot arrays
@@ -367,7 +377,7 @@ namespace
         std::memset(&A, 0, sizeof(A));
         auto& own = ctx->slotAllocations;
         int rc;
-        double** dbl[] = {&A.rx, &A.ry, &A.rz, &A.kx, &A.ky, &A.kz, &A.lambda, &A.W, &A.Lthreshold, &A.taupath, &A.rngSpare, &A.sint,
+        double** dbl[] = {&A.rx, &A.ry, &A.rz, &A.kx, &A.ky, &A.kz, &A.lambda, &A.W, &A.Lthreshold, &A.taupath, &A.tausample, &A.rngSpare, &A.sint,
                           &A.nint};
         for (double** d : dbl)
             if ((rc = ctx->allocate<double>(n, d, false, &own))) return rc;
@@ -400,6 +410,7 @@ namespace
         // launch lists: per group PMC_LAUNCH_SHARDS regions whose capacities add up to at most group size + 65536
         if ((rc = ctx->allocate<int32_t>(size_t(n) + size_t(PMC_MAX_GROUPS) * 65536, &K.launchList, false, &own))) return rc;
         if ((rc = ctx->allocate<uint32_t>(nt, &K.bits, false, &own))) return rc;
+    if (ctx->dev.grid_kind == PMC_GRID_OCTREE && (rc = ctx->allocate<uint64_t>(nt, &K.pidx, false, &own))) return rc;
         A.num_slots = n;
         ctx->allocatedSlots = n;
         ctx->sceneDirty = true;
@@ -429,7 +440,11 @@ void pmc_destroy(pmc_ctx* ctx)
 {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (int g = 0; g < PMC_MAX_GROUPS; ++g)
+    {
+        if (ctx->groupStream[g]) hipStreamSynchronize(ctx->groupStream[g]);
+        if (ctx->peelStream[g]) hipStreamSynchronize(ctx->peelStream[g]);
+    }
     for (void* p : ctx->allocations) hipFree(p);
     for (void* p : ctx->slotAllocations) hipFree(p);
     if (ctx->pinned) hipHostFree(ctx->pinned);
@@ -437,12 +452,17 @@ void pmc_destroy(pmc_ctx* ctx)
         if (e) hipEventDestroy(e);
     for (int g = 0; g < PMC_MAX_GROUPS; ++g)
     {
-        for (hipEvent_t e : {ctx->evA[g], ctx->evB[g], ctx->evC[g]})
+        for (hipEvent_t e : {ctx->evA[g], ctx->evB[g], ctx->evC[g], ctx->evJoin[g]})
             if (e) hipEventDestroy(e);
         if (g > 0 && ctx->groupStream[g]) hipStreamDestroy(ctx->groupStream[g]);
+        if (ctx->peelStream[g]) hipStreamDestroy(ctx->peelStream[g]);
     }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
-    if (ctx->slot >= 0) g_slotUsed[ctx->slot] = false;
+    if (ctx->slot >= 0)
+    {
+        std::lock_guard<std::mutex> lock(g_slotMutex);
+        g_slotUsed[ctx->device][ctx->slot] = false;
+    }
     delete ctx;
 }
 
@@ -464,14 +484,18 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     if (device < 0 || device >= count) return fail(PMC_ERR_INVALID, "invalid device index");
     HIP_TRY(hipSetDevice(device));
 
+    if (device >= MAX_DEVICES) return fail(PMC_ERR_UNSUPPORTED, "device index beyond the context table");
     pmc_ctx* ctx = new pmc_ctx();
     ctx->device = device;
-    for (int sl = 0; sl < PMC_MAX_CONTEXTS && ctx->slot < 0; ++sl)
-        if (!g_slotUsed[sl])
-        {
-            g_slotUsed[sl] = true;
-            ctx->slot = sl;
-        }
+    {
+        std::lock_guard<std::mutex> lock(g_slotMutex);
+        for (int sl = 0; sl < PMC_MAX_CONTEXTS && ctx->slot < 0; ++sl)
+            if (!g_slotUsed[device][sl])
+            {
+                g_slotUsed[device][sl] = true;
+                ctx->slot = sl;
+            }
+    }
     if (ctx->slot < 0)
     {
         delete ctx;
@@ -486,10 +510,12 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     ctx->groupStream[0] = ctx->stream;
     for (int g = 1; g < PMC_MAX_GROUPS; ++g)
         if (hipStreamCreate(&ctx->groupStream[g]) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipStreamCreate failed"));
+    for (int g = 0; g < PMC_MAX_GROUPS; ++g)
+        if (hipStreamCreate(&ctx->peelStream[g]) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipStreamCreate failed"));
     for (hipEvent_t* ev : {&ctx->evStart, &ctx->evStop})
         if (hipEventCreate(ev) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipEventCreate failed"));
     for (int g = 0; g < PMC_MAX_GROUPS; ++g)
-        for (hipEvent_t* ev : {&ctx->evA[g], &ctx->evB[g], &ctx->evC[g]})
+        for (hipEvent_t* ev : {&ctx->evA[g], &ctx->evB[g], &ctx->evC[g], &ctx->evJoin[g]})
             if (hipEventCreate(ev) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipEventCreate failed"));
     if (const char* env = getenv("PMC_NUM_GROUPS")) ctx->numGroups = std::min(PMC_MAX_GROUPS, std::max(1, atoi(env)));
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), 16 * sizeof(unsigned long long)) != hipSuccess)
@@ -560,8 +586,8 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if ((rc = buildTree(g, scene->medium.number_density, T))) return bail(rc);
         D.lmax = T.lmax;
         D.root_link = T.rootLink;
-        if (g.num_cells > (1 << 25) || T.internals.size() > (size_t(1) << 26))
-            return bail(fail(PMC_ERR_UNSUPPORTED, "octree with more than 2^25 cells (32-bit record offsets, 27-bit link index)"));
+        if (T.cellSlots >= (1 << 24) || T.internals.size() > (size_t(1) << 26))
+            return bail(fail(PMC_ERR_UNSUPPORTED, "octree with 2^24 cells or more (24-bit table index arithmetic, 27-bit link index)"));
         D.tab_stride_bytes = 8u * uint32_t(T.tabn);
         D.fine_scale[0] = double(1 << T.lmax) / (g.xmax - g.xmin);
         D.fine_scale[1] = double(1 << T.lmax) / (g.ymax - g.ymin);
@@ -665,6 +691,12 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         const pmc_instrument& I = scene->instruments[i];
         DevInstrument& d = D.inst[i];
         d.kx = I.kobs[0], d.ky = I.kobs[1], d.kz = I.kobs[2];
+        // RN(1/k) as PathSegmentGenerator's users divide by it; an axis with |k| <= 1e-15 is ignored (TreeSpatialGrid.cpp:160-175)
+        const double ignored = std::nan("");
+        d.ikx = std::fabs(d.kx) > 1e-15 ? 1. / d.kx : ignored;
+        d.iky = std::fabs(d.ky) > 1e-15 ? 1. / d.ky : ignored;
+        d.ikz = std::fabs(d.kz) > 1e-15 ? 1. / d.kz : ignored;
+        d.sgn = (d.kx < 0. ? 1u : 0u) | (d.ky < 0. ? 2u : 0u) | (d.kz < 0. ? 4u : 0u);
         d.costheta = I.costheta, d.sintheta = I.sintheta, d.cosphi = I.cosphi, d.sinphi = I.sinphi;
         d.cosomega = I.cosomega, d.sinomega = I.sinomega;
         d.xpmin = I.xpmin, d.xpsiz = I.xpsiz, d.ypmin = I.ypmin, d.ypsiz = I.ypsiz;
@@ -727,14 +759,23 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipGetDeviceProperties failed"));
     ctx->numCU = prop.multiProcessorCount;
     ctx->block = 256;
-    int perCU = pmcWalkBlocksPerCU(D.grid_kind, ctx->block, ctx->walkLds);
-    if (perCU < 1) perCU = 1;
-    // Three workgroups per CU (three waves per SIMD at 149 VGPRs): measured best with the 64-byte cell records
-    // (profiles/README.md); the transition / launch kernels of the other slot group get the CUs between generations.
-    int wantPerCU = 3;
-    if (const char* env = getenv("PMC_WALK_BLOCKS_PER_CU")) wantPerCU = std::max(1, atoi(env));  // tuning aid
-    perCU = std::min(perCU, wantPerCU);
-    ctx->grid = ctx->numCU * perCU;
+    ctx->wide = D.grid_kind == PMC_GRID_OCTREE && D.lmax > 10;
+    {
+        // persistent walk kernels: as many workgroups as stay resident (the transition / launch kernels of the other
+        // slot group get the CUs between generations)
+        int perCU = pmcWalkBlocksPerCU(D.grid_kind, D.grid_kind == PMC_GRID_OCTREE ? 2 : 0, ctx->wide, ctx->block, ctx->walkLds);
+        if (perCU < 1) perCU = 1;
+        if (const char* env = getenv("PMC_WALK_BLOCKS_PER_CU")) perCU = std::min(perCU, std::max(1, atoi(env)));  // tuning aid
+        else if (D.grid_kind != PMC_GRID_OCTREE) perCU = std::min(perCU, 3);
+        ctx->grid = ctx->numCU * perCU;
+        if (D.grid_kind == PMC_GRID_OCTREE)
+        {
+            int peelPerCU = pmcWalkBlocksPerCU(D.grid_kind, 1, ctx->wide, pmcPeelBlock(), ctx->walkLds);
+            if (peelPerCU < 1) peelPerCU = 1;
+            if (const char* env = getenv("PMC_PEEL_BLOCKS_PER_CU")) peelPerCU = std::min(peelPerCU, std::max(1, atoi(env)));
+            ctx->peelGrid = ctx->numCU * peelPerCU;
+        }
+    }
 
     // ---- packet slots
     int64_t slots = 8 * 1024 * 1024;  // about 1 KB of state per slot
@@ -831,7 +872,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         }
     }
     HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_HISTORY, 0, sizeof(unsigned long long), st));
-    HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(0), 0, 4 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(ctr + 32, 0, 4 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(0, 0), 0, 8 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(ctx->evStart, st));
     const int launchGrid = std::max(1, ctx->numCU * 4) / PMC_LAUNCH_SHARDS * PMC_LAUNCH_SHARDS + PMC_LAUNCH_SHARDS;
     int transitionBlocks = ctx->numCU * 4;  // persistent transition workgroups (tables staged once per workgroup)
@@ -846,10 +888,25 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         const int listBase = base[g] + g * 65536;
         if (!initial)
         {
-            HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(g), 0, sizeof(unsigned long long), sg));  // task cursor
+            HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(g, 0), 0, 8 * sizeof(unsigned long long), sg));  // task cursors
             HIP_TRY(hipEventRecord(ctx->evA[g], sg));
-            HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, D.rf_store, base[g], size[g], PMC_CTR_TASK(g), seed, ctx->grid, ctx->block, ctx->walkLds,
-                                  sg));
+            if (D.grid_kind == PMC_GRID_OCTREE)
+            {
+                // the walks of the generation: one peel-off kernel per observer on the group's side stream, next to the
+                // propagation kernel on the group's stream (they touch different task records and result fields)
+                hipStream_t sp = ctx->peelStream[g];
+                if (getenv("PMC_SERIAL_WALKS")) sp = sg;  // tuning aid: peel-off and propagation kernels one after the other
+                HIP_TRY(hipStreamWaitEvent(sp, ctx->evA[g], 0));
+                for (int i = 0; i < D.num_instruments; ++i)
+                    if (!D.inst[i].same_observer)
+                        HIP_TRY(pmcLaunchPeel(ctx->slot, ctx->wide, base[g], size[g], PMC_CTR_TASK(g, 1 + i), i, ctx->peelGrid, ctx->walkLds, sp));
+                HIP_TRY(hipEventRecord(ctx->evJoin[g], sp));
+                HIP_TRY(pmcLaunchProp(ctx->slot, ctx->wide, D.rf_store, base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->walkLds, sg));
+                HIP_TRY(hipStreamWaitEvent(sg, ctx->evJoin[g], 0));
+            }
+            else
+                HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, D.rf_store, base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->block,
+                                      ctx->walkLds, sg));
             haveWalk[g] = true;
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_LIVE(g), 0, sizeof(unsigned long long), sg));
@@ -870,36 +927,46 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         HIP_TRY(hipMemcpyAsync(ctx->pinned + g, ctr + PMC_CTR_LIVE(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
         return PMC_OK;
     };
-    for (int g = 0; g < G; ++g)
-        if (active[g])
+    // on any failure: no kernel of this segment may still be running (or be timed) when the call returns
+    auto abandon = [&](int code) {
+        hipDeviceSynchronize();
+        ctx->timed = false;
+        return code;
+    };
+    auto drive = [&]() -> int {
+        for (int g = 0; g < G; ++g)
+            if (active[g])
+            {
+                int rc = enqueue(g, true);
+                if (rc) return rc;
+            }
+        int remaining = 0;
+        for (int g = 0; g < G; ++g) remaining += active[g] ? 1 : 0;
+        for (int g = 0; remaining > 0; g = (g + 1) % G)
         {
-            int rc = enqueue(g, true);
+            if (!active[g]) continue;
+            HIP_TRY(hipStreamSynchronize(ctx->groupStream[g]));
+            float ms = 0;
+            if (haveWalk[g])
+            {
+                HIP_TRY(hipEventElapsedTime(&ms, ctx->evA[g], ctx->evB[g]));
+                walkMs += ms;
+            }
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->evB[g], ctx->evC[g]));
+            transMs += ms;
+            if (ctx->pinned[g] == 0)
+            {
+                active[g] = false;
+                --remaining;
+                continue;
+            }
+            ++generations;
+            int rc = enqueue(g, false);
             if (rc) return rc;
         }
-    int remaining = 0;
-    for (int g = 0; g < G; ++g) remaining += active[g] ? 1 : 0;
-    for (int g = 0; remaining > 0; g = (g + 1) % G)
-    {
-        if (!active[g]) continue;
-        HIP_TRY(hipStreamSynchronize(ctx->groupStream[g]));
-        float ms = 0;
-        if (haveWalk[g])
-        {
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->evA[g], ctx->evB[g]));
-            walkMs += ms;
-        }
-        HIP_TRY(hipEventElapsedTime(&ms, ctx->evB[g], ctx->evC[g]));
-        transMs += ms;
-        if (ctx->pinned[g] == 0)
-        {
-            active[g] = false;
-            --remaining;
-            continue;
-        }
-        ++generations;
-        int rc = enqueue(g, false);
-        if (rc) return rc;
-    }
+        return PMC_OK;
+    };
+    if (int rc = drive()) return abandon(rc);
     HIP_TRY(hipEventRecord(ctx->evStop, st));
     HIP_TRY(hipEventSynchronize(ctx->evStop));
     HIP_TRY(hipEventElapsedTime(&ctx->totalMs, ctx->evStart, ctx->evStop));
@@ -1011,24 +1078,31 @@ int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out)
     out->scatterings = host[4];
     out->stat_overflows = host[5];
     out->rewalk_visits = host[6];
-    if (getenv("PMC_DEBUG_DUMP")) fprintf(stderr, "PMC_DEBUG flush: short %llu long %llu short_ell_neg %llu\n", host[60], host[61], host[62]);
     if (getenv("PMC_PROFILE_DUMP"))
     {
+        // work counters of the octree walk kernels: lane utilisation = lane_steps / (64 wave_steps)
+        const unsigned long long* w = host + PMC_CTR_WALKWORK;
+        fprintf(stderr, "PMC_PROFILE peel: wave_steps %llu lane_steps %llu (%.1f %% of the lanes) service_rounds %llu\n", w[0], w[1],
+                w[0] ? 100. * double(w[1]) / (64. * double(w[0])) : 0., w[2]);
+        fprintf(stderr, "PMC_PROFILE prop: wave_steps %llu lane_steps %llu (%.1f %% of the lanes) service_rounds %llu\n", w[3], w[4],
+                w[3] ? 100. * double(w[4]) / (64. * double(w[3])) : 0., w[5]);
+    }
+#ifdef PMC_PROFILE
+    if (getenv("PMC_PROFILE_DUMP"))
+    {
+        for (int k = 0; k < 2; ++k)
+        {
+            const unsigned long long* t = host + 88 + 8 * k;
+            fprintf(stderr, "PMC_PROFILE %s phases (wave cycles): gather %llu tau+position %llu descent %llu walls %llu inside+exit %llu "
+                            "service-finish+claim %llu service-loads %llu loop %llu\n", k ? "prop" : "peel", t[0], t[1], t[2], t[3], t[4], t[5],
+                    t[6], t[7]);
+        }
         fprintf(stderr, "PMC_PROFILE transition (wave cycles): stage %llu mode-load %llu cycle-tail %llu append %llu loads+detect %llu scatter %llu start-cycle %llu flush %llu\n",
                 host[40], host[41], host[42], host[43], host[44], host[45], host[46], host[47]);
         fprintf(stderr, "PMC_PROFILE launch (wave cycles): stage %llu list %llu stats-flush %llu start-cycle %llu draw+sample %llu - %llu flush %llu\n",
                 host[48], host[49], host[50], host[51], host[52], host[53], host[54]);
     }
-    if (getenv("PMC_PROFILE_DUMP"))
-        fprintf(stderr,
-                "PMC_PROFILE walk: service_cycles %llu step_cycles %llu services %llu wave_steps %llu lane_steps %llu slow_lanes %llu\n",
-                host[11], host[12], host[13], host[14], host[15], host[26]);
-    if (getenv("PMC_PROFILE_DUMP"))
-        fprintf(stderr, "PMC_PROFILE walk tail (after the task list is exhausted): wave_steps %llu lane_steps %llu wave_cycles %llu max_wave_cycles(last launch accumulates) %llu\n",
-                host[56], host[57], host[58], host[59]);
-    if (getenv("PMC_PROFILE_DUMP"))
-        fprintf(stderr, "PMC_PROFILE walk step phases (lane-0 cycles): pre-link %llu link-wait %llu descend %llu head-wait %llu enter %llu\n",
-                host[27], host[28], host[29], host[30], host[31]);
+#endif
     return PMC_OK;
 }
 
@@ -1044,35 +1118,54 @@ int pmc_trace_ray(pmc_ctx* ctx, const double r[3], const double k[3], int32_t* m
 {
     if (!ctx || !r || !k || !m || !ds || !n || cap < 0) return fail(PMC_ERR_INVALID, "invalid argument");
     HIP_TRY(hipSetDevice(ctx->device));
+    // octree: the ray is traced with BOTH flavours of the step (direction in scalar registers as in the peel-off kernel,
+    // in vector registers as in the propagation kernel); they must agree bit for bit
+    const int flavours = ctx->dev.grid_kind == PMC_GRID_OCTREE ? 2 : 1;
+    const size_t room = size_t(std::max(cap, 1));
     int32_t* dm = nullptr;
     double* dds = nullptr;
     int32_t* dn = nullptr;
-    HIP_TRY(hipMalloc(&dm, sizeof(int32_t) * std::max(cap, 1)));
-    HIP_TRY(hipMalloc(&dds, sizeof(double) * std::max(cap, 1)));
-    HIP_TRY(hipMalloc(&dn, sizeof(int32_t)));
-    hipError_t e = hipSuccess;
-    if (ctx->sceneDirty)
+    double* dk = nullptr;
+    HIP_TRY(hipMalloc(&dm, sizeof(int32_t) * room * flavours));
+    HIP_TRY(hipMalloc(&dds, sizeof(double) * room * flavours));
+    HIP_TRY(hipMalloc(&dn, sizeof(int32_t) * flavours));
+    HIP_TRY(hipMalloc(&dk, sizeof(double) * 3));
+    hipError_t e = hipMemcpy(dk, k, 3 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && ctx->sceneDirty)
     {
         e = hipStreamSynchronize(ctx->stream);
         if (e == hipSuccess) e = pmcUploadScene(ctx->slot, &ctx->dev, ctx->stream);
         if (e == hipSuccess) ctx->sceneDirty = false;
     }
-    if (e == hipSuccess)
-        e = pmcLaunchTrace(ctx->slot, ctx->dev.grid_kind, r, k, dm, dds, cap, dn, ctx->walkLds, ctx->stream);
+    for (int f = 0; f < flavours && e == hipSuccess; ++f)
+        e = pmcLaunchTrace(ctx->slot, ctx->dev.grid_kind, ctx->wide, f, r, k, dk, dm + f * room, dds + f * room, cap, dn + f, ctx->walkLds,
+                           ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     int rc = PMC_OK;
     if (e != hipSuccess)
         rc = hipFail(e, "trace kernel");
     else
     {
-        hipMemcpy(n, dn, sizeof(int32_t), hipMemcpyDeviceToHost);
-        int32_t got = std::min(*n, cap);
+        int32_t count[2] = {0, 0};
+        hipMemcpy(count, dn, sizeof(int32_t) * flavours, hipMemcpyDeviceToHost);
+        *n = count[0];
+        const int32_t got = std::min(*n, cap);
         hipMemcpy(m, dm, sizeof(int32_t) * got, hipMemcpyDeviceToHost);
         hipMemcpy(ds, dds, sizeof(double) * got, hipMemcpyDeviceToHost);
+        if (flavours == 2)
+        {
+            std::vector<int32_t> m2(got);
+            std::vector<double> ds2(got);
+            hipMemcpy(m2.data(), dm + room, sizeof(int32_t) * got, hipMemcpyDeviceToHost);
+            hipMemcpy(ds2.data(), dds + room, sizeof(double) * got, hipMemcpyDeviceToHost);
+            if (count[1] != count[0] || std::memcmp(m2.data(), m, sizeof(int32_t) * got) || std::memcmp(ds2.data(), ds, sizeof(double) * got))
+                rc = fail(PMC_ERR_DEVICE, "octree traversal: the scalar-direction and vector-direction steps disagree on this ray");
+        }
     }
     hipFree(dm);
     hipFree(dds);
     hipFree(dn);
+    hipFree(dk);
     return rc;
 }
 }

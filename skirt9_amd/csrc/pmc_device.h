@@ -62,6 +62,8 @@ static_assert(sizeof(NodeRec) == 64, "NodeRec must be one 64-byte record");
 struct DevInstrument
 {
     double kx, ky, kz;
+    double ikx, iky, ikz;   // RN(1/k) of the observer direction, NaN for an ignored axis (|k| <= 1e-15): the peel-off walks
+    uint32_t sgn;           // bit a: k_a < 0
     double costheta, sintheta, cosphi, sinphi, cosomega, sinomega;
     double xpmin, xpsiz, ypmin, ypsiz;
     int32_t nxp, nyp;
@@ -90,6 +92,7 @@ struct SlotArrays
     double* ppW;                            // [PMC_MAX_INSTRUMENTS][num_slots] weight of the cycle's peel-off packet towards
                                             // the observer whose instrument group starts at that instrument
     double* taupath;                        // optical depth of the whole path (pass 1), kept for the escape weight
+    double* tausample;                      // interaction optical depth sampled between the passes (path-length-bias weight)
     uint64_t* history;
     double*  rngSpare;
     uint32_t* rngBlock;                     // (block << 1) | have
@@ -129,7 +132,10 @@ struct TaskArrays
     double* sext;                           // extinction cross section at the packet's wavelength
     int32_t* cell;                          // first cell
     uint32_t* bits;                         // mode (bits 0-1) | exit axis (2-3) | direction signs (4-6) | size exponent (8-11)
-    int32_t* cijk;                          // Cartesian only: cell indices i | j << 10 | k << 20
+                                            // (octree peel-off records hold position, ds, target, sext, cell, pidx, bits only:
+                                            // their direction is the observer's)
+    int32_t* cijk;                          // Cartesian: cell indices i | j << 10 | k << 20; Voronoi: exit neighbour
+    uint64_t* pidx;                         // octree: packed fine lower-corner indices of the first cell (Walk::P)
     int32_t* launchList;                    // slots whose history has ended (consumed by the launch kernel): per slot group
                                             // PMC_LAUNCH_SHARDS regions of shard_cap entries, counted by DevScene::launch_count
 };
@@ -240,11 +246,14 @@ struct DevScene
     int32_t dust_in_lds;
 };
 
-#define PMC_NUM_COUNTERS 64
+#define PMC_NUM_COUNTERS 128
 #define PMC_CTR_HISTORY 8
-// per slot group g: cursor of the walk kernel over the task records, live slots
-#define PMC_CTR_TASK(g) (32 + 4 * (g))
+// [16..21] work of the octree walk kernels: peel-off wave-steps, lane-steps, service rounds; propagation likewise
+#define PMC_CTR_WALKWORK 16
+// per slot group g: live slots; cursors of the walk kernels over the slots of the group (k = 0: the generic / propagation
+// kernel, k = 1 + observer: the peel-off kernel of that observer)
 #define PMC_CTR_LIVE(g) (35 + 4 * (g))
+#define PMC_CTR_TASK(g, k) (64 + 8 * (g) + (k))
 #define PMC_MAX_GROUPS 4
 #define PMC_TRANSITION_ALIGN 1024  // slot groups start at multiples of the transition kernel's workgroup size
 

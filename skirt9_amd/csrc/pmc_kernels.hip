@@ -50,10 +50,26 @@
 #include <float.h>
 #include <math.h>
 #include <algorithm>
+#include <type_traits>
 
 #ifndef PMC_WALK_REFILL
     #define PMC_WALK_REFILL 40  // waiting (idle or pending) lanes in a wave that trigger a service round (a round costs
                                 // several hundred instructions whatever the number of lanes it serves)
+#endif
+#ifndef PMC_PEEL_REFILL
+    #define PMC_PEEL_REFILL 16  // octree peel-off kernel: waiting lanes that trigger a (cheap) service round
+#endif
+#ifndef PMC_PROP_REFILL
+    #define PMC_PROP_REFILL 24  // octree propagation kernel: likewise (its round includes the pass-1 -> pass-2 sampling)
+#endif
+#ifndef PMC_PEEL_BLOCK
+    #define PMC_PEEL_BLOCK 512  // lanes per workgroup of the peel-off kernel (one coordinate table in LDS per workgroup)
+#endif
+#ifndef PMC_PEEL_MIN_WAVES
+    #define PMC_PEEL_MIN_WAVES 8  // waves per SIMD the peel-off kernel's register budget must allow (<= 64 VGPRs)
+#endif
+#ifndef PMC_PROP_MIN_WAVES
+    #define PMC_PROP_MIN_WAVES 4  // likewise for the propagation kernel (<= 128 VGPRs)
 #endif
 #ifndef PMC_WALK_MIN_WAVES
     #define PMC_WALK_MIN_WAVES 1  // waves per SIMD the walk kernel's register budget must allow
@@ -74,7 +90,9 @@
     #define PMC_TRANSITION_BLOCK 256  // lanes per workgroup of the transition kernel: 256 measured 4 % faster than 512
                                       // (profiles/README.md); small enough to share a CU with the walk kernel
 #endif
-#define PMC_TASK_CHUNK 128   // slots a wave takes from the global cursor at a time
+#ifndef PMC_TASK_CHUNK
+    #define PMC_TASK_CHUNK 128  // slots a wave takes from the global cursor at a time
+#endif
 
 // the scene of every live context, in constant memory: all accesses are scalar loads
 __constant__ DevScene c_scene[PMC_MAX_CONTEXTS];
@@ -154,6 +172,7 @@ namespace
     }
 
 #include "pmc_walk.inc"
+#include "pmc_walk_tree.inc"
 #include "pmc_transition.inc"
 }
 
@@ -166,27 +185,39 @@ extern "C" hipError_t pmcUploadScene(int slot, const DevScene* scene, hipStream_
                                   hipMemcpyHostToDevice, stream);
 }
 
+// the dynamic-LDS limit is a property of the kernel, not of a context: it is only ever raised (a small scene created
+// after a large one must not lower the limit under the live context)
 extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
 {
+    static size_t walkMax = 0, transitionMax = 0;
+    walkMax = std::max(walkMax, walkLds);
+    transitionMax = std::max(transitionMax, transitionLds);
     const struct
     {
         const void* kernel;
         size_t lds;
-    } all[] = {{reinterpret_cast<const void*>(&walkKernel<GRID_TREE, false>), walkLds},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, false>), walkLds},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_TREE, true>), walkLds},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, true>), walkLds},
-               {reinterpret_cast<const void*>(&traceRayKernel<GRID_TREE>), walkLds},
-               {reinterpret_cast<const void*>(&traceRayKernel<GRID_CART>), walkLds},
-               {reinterpret_cast<const void*>(&transitionKernel<GRID_TREE>), transitionLds},
-               {reinterpret_cast<const void*>(&transitionKernel<GRID_CART>), transitionLds},
-               {reinterpret_cast<const void*>(&launchKernel<GRID_TREE>), transitionLds},
-               {reinterpret_cast<const void*>(&launchKernel<GRID_CART>), transitionLds},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false>), walkLds},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, true>), walkLds},
-               {reinterpret_cast<const void*>(&traceRayKernel<GRID_VORO>), walkLds},
-               {reinterpret_cast<const void*>(&transitionKernel<GRID_VORO>), transitionLds},
-               {reinterpret_cast<const void*>(&launchKernel<GRID_VORO>), transitionLds}};
+    } all[] = {{reinterpret_cast<const void*>(&walkPeelKernel<false>), walkMax},
+               {reinterpret_cast<const void*>(&walkPeelKernel<true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, true>), walkMax},
+               {reinterpret_cast<const void*>(&traceTreeKernel<false, false>), walkMax},
+               {reinterpret_cast<const void*>(&traceTreeKernel<false, true>), walkMax},
+               {reinterpret_cast<const void*>(&traceTreeKernel<true, false>), walkMax},
+               {reinterpret_cast<const void*>(&traceTreeKernel<true, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, true>), walkMax},
+               {reinterpret_cast<const void*>(&traceRayKernel<GRID_CART>), walkMax},
+               {reinterpret_cast<const void*>(&transitionKernel<GRID_TREE>), transitionMax},
+               {reinterpret_cast<const void*>(&transitionKernel<GRID_CART>), transitionMax},
+               {reinterpret_cast<const void*>(&launchKernel<GRID_TREE>), transitionMax},
+               {reinterpret_cast<const void*>(&launchKernel<GRID_CART>), transitionMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, true>), walkMax},
+               {reinterpret_cast<const void*>(&traceRayKernel<GRID_VORO>), walkMax},
+               {reinterpret_cast<const void*>(&transitionKernel<GRID_VORO>), transitionMax},
+               {reinterpret_cast<const void*>(&launchKernel<GRID_VORO>), transitionMax}};
     for (const auto& k : all)
     {
         hipError_t e = hipFuncSetAttribute(k.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds);
@@ -195,12 +226,18 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
     return hipSuccess;
 }
 
-extern "C" int pmcWalkBlocksPerCU(int gridKind, int block, size_t ldsBytes)
+// resident workgroups per CU of a walk kernel: kind 0 = generic (Cartesian / Voronoi), 1 = octree peel-off, 2 = octree
+// propagation
+extern "C" int pmcWalkBlocksPerCU(int gridKind, int kind, int wide, int block, size_t ldsBytes)
 {
     int n = 0;
     hipError_t e;
-    if (gridKind == PMC_GRID_OCTREE)
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_TREE, false>), block, ldsBytes);
+    if (gridKind == PMC_GRID_OCTREE && kind == 1)
+        e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPeelKernel<true>), block, ldsBytes)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPeelKernel<false>), block, ldsBytes);
+    else if (gridKind == PMC_GRID_OCTREE)
+        e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<true, false>), block, ldsBytes)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<false, false>), block, ldsBytes);
     else if (gridKind == PMC_GRID_VORONOI)
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false>), block, ldsBytes);
     else
@@ -208,16 +245,39 @@ extern "C" int pmcWalkBlocksPerCU(int gridKind, int block, size_t ldsBytes)
     return e == hipSuccess ? n : 0;
 }
 
-// walks of the task records [taskBase, taskBase + numTaskRecords) of one slot group; taskCounter = index of the
-// group's (zeroed) cursor
+extern "C" int pmcPeelBlock(void)
+{
+    return PMC_PEEL_BLOCK;
+}
+
+// walks of the task records [taskBase, taskBase + numTaskRecords) of one slot group on a Cartesian or Voronoi grid;
+// taskCounter = index of the group's (zeroed) cursor
 extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int taskBase, int numTaskRecords, int taskCounter,
                                     uint64_t seed, int grid, int block, size_t ldsBytes, hipStream_t stream)
 {
     // (the radiation-field flavour is a separate instantiation: the plain photon loop pays nothing for it)
-    auto kernel = gridKind == PMC_GRID_OCTREE    ? (storeRf ? walkKernel<GRID_TREE, true> : walkKernel<GRID_TREE, false>)
-                  : gridKind == PMC_GRID_VORONOI ? (storeRf ? walkKernel<GRID_VORO, true> : walkKernel<GRID_VORO, false>)
-                                                 : (storeRf ? walkKernel<GRID_CART, true> : walkKernel<GRID_CART, false>);
+    auto kernel = gridKind == PMC_GRID_VORONOI ? (storeRf ? walkKernel<GRID_VORO, true> : walkKernel<GRID_VORO, false>)
+                                               : (storeRf ? walkKernel<GRID_CART, true> : walkKernel<GRID_CART, false>);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter, seed);
+    return hipGetLastError();
+}
+
+// octree: the peel-off walks towards observer `obs` of the slots [slotBase, slotBase + numSlots)
+extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, int cursor, int obs, int grid, size_t ldsBytes,
+                                    hipStream_t stream)
+{
+    auto kernel = wide ? walkPeelKernel<true> : walkPeelKernel<false>;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PEEL_BLOCK), ldsBytes, stream, slot, slotBase, numSlots, cursor, obs);
+    return hipGetLastError();
+}
+
+// octree: the propagation walks of the slots [slotBase, slotBase + numSlots)
+extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, int cursor, uint64_t seed, int grid,
+                                    size_t ldsBytes, hipStream_t stream)
+{
+    auto kernel = wide ? (storeRf ? walkPropKernel<true, true> : walkPropKernel<true, false>)
+                       : (storeRf ? walkPropKernel<false, true> : walkPropKernel<false, false>);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, cursor, seed);
     return hipGetLastError();
 }
 
@@ -258,12 +318,19 @@ extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int 
     return hipGetLastError();
 }
 
-extern "C" hipError_t pmcLaunchTrace(int slot, int gridKind, const double r[3], const double k[3], int32_t* m, double* ds,
-                                     int32_t cap, int32_t* n, size_t ldsBytes, hipStream_t stream)
+// one ray through the grid; octree: `uniform` picks the flavour of the step the ray is traced with (direction in scalar
+// registers as in the peel-off kernel, or in vector registers as in the propagation kernel; kdev = the direction in
+// device memory)
+extern "C" hipError_t pmcLaunchTrace(int slot, int gridKind, int wide, int uniform, const double r[3], const double k[3],
+                                     const double* kdev, int32_t* m, double* ds, int32_t cap, int32_t* n, size_t ldsBytes,
+                                     hipStream_t stream)
 {
     if (gridKind == PMC_GRID_OCTREE)
-        hipLaunchKernelGGL(traceRayKernel<GRID_TREE>, dim3(1), dim3(64), ldsBytes, stream, slot, r[0], r[1], r[2], k[0], k[1],
-                           k[2], m, ds, cap, n);
+    {
+        auto kernel = wide ? (uniform ? traceTreeKernel<true, true> : traceTreeKernel<true, false>)
+                           : (uniform ? traceTreeKernel<false, true> : traceTreeKernel<false, false>);
+        hipLaunchKernelGGL(kernel, dim3(1), dim3(64), ldsBytes, stream, slot, r[0], r[1], r[2], k[0], k[1], k[2], kdev, m, ds, cap, n);
+    }
     else if (gridKind == PMC_GRID_VORONOI)
         hipLaunchKernelGGL(traceRayKernel<GRID_VORO>, dim3(1), dim3(64), ldsBytes, stream, slot, r[0], r[1], r[2], k[0], k[1],
                            k[2], m, ds, cap, n);

@@ -2,10 +2,9 @@
 //
 // Restated so that tables built at setup time come out bit-identical to the reference's (same formulas, same
 // operation order, IEEE double, glibc libm):
-//   locate / locateClip / locateFail, interpolation, clamped resampling, cdf   SKIRT/utils/NR.hpp:130-190,203-209,
-//                                                                             300-306,328-362,373-436,446-475
-//   cdf2 (log-log / lin-lin cumulative)                                        SKIRT/utils/NR.cpp:25-54
-//   lngamma, gamma, gln, gexp                                                  SKIRT/utils/SpecialFunctions.cpp:11-30,798-836
+//   tab::     bracketing, interpolation, clamped resampling, cumulative         SKIRT/utils/NR.hpp:130-190,203-209,
+//             distributions                                                     300-306,328-362,373-436,446-475; NR.cpp:25-54
+//   special:: lngamma, gamma, gln, gexp                                         SKIRT/utils/SpecialFunctions.cpp:11-30,798-836
 //   Random: mt19937_64 + uniform_real_distribution(nextafter(0,1), 1)          SKIRT/core/Random.cpp:18-54,70-73
 #ifndef SKH_MATHUTIL_HPP
 #define SKH_MATHUTIL_HPP
@@ -51,157 +50,167 @@ namespace skh
         }
     };
 
-    namespace nr
+    // ---- ordered tables: bracketing, interpolation, resampling.  Semantics of the reference's table helpers
+    // (SKIRT/utils/NR.hpp:130-190,203-209,300-306,328-362,373-436,446-475), which the setup-time tables depend on.
+    namespace tab
     {
-        inline int locateBasic(const Array& xv, double x, int n)
+        // largest index i in [-1, limit) with table[i] <= x (table ascending); -1 if x lies below the first entry
+        inline int lastNotAbove(const Array& table, double x, int limit)
         {
-            int jl = -1;
-            int ju = n;
-            while (ju - jl > 1)
+            int below = -1, above = limit;
+            while (above - below > 1)
             {
-                int jm = (ju + jl) >> 1;
-                if (x < xv[jm])
-                    ju = jm;
-                else
-                    jl = jm;
+                const int middle = (above + below) >> 1;
+                (x < table[middle] ? above : below) = middle;
             }
-            return jl;
+            return below;
         }
-        inline int locate(const Array& xv, double x)
+        // interval [table[i], table[i+1]) that holds x; the last interval is closed; -1 below, size-1 above the table
+        inline int bracket(const Array& table, double x)
         {
-            int n = static_cast<int>(xv.size());
-            if (x == xv[n - 1]) return n - 2;
-            return locateBasic(xv, x, n);
+            const int count = static_cast<int>(table.size());
+            return x == table[count - 1] ? count - 2 : lastNotAbove(table, x, count);
         }
-        inline int locateClip(const Array& xv, double x)
+        // the same, with values outside the table assigned to the first / last interval
+        inline int bracketClipped(const Array& table, double x)
         {
-            int n = static_cast<int>(xv.size());
-            if (x < xv[0]) return 0;
-            return locateBasic(xv, x, n - 1);
+            const int count = static_cast<int>(table.size());
+            return x < table[0] ? 0 : lastNotAbove(table, x, count - 1);
         }
-        inline int locateFail(const Array& xv, double x)
+        // the same, but -1 for a value above the table
+        inline int bracketOrMiss(const Array& table, double x)
         {
-            int n = static_cast<int>(xv.size());
-            if (x > xv[n - 1]) return -1;
-            return locateBasic(xv, x, n - 1);
+            const int count = static_cast<int>(table.size());
+            return x > table[count - 1] ? -1 : lastNotAbove(table, x, count - 1);
         }
-        inline double linearGrid(Array& xv, double xmin, double xmax, int n)
+        // count + 1 equidistant points from first to last; returns the spacing
+        inline double linearGrid(Array& points, double first, double last, int count)
         {
-            xv.resize(n + 1);
-            double dx = (xmax - xmin) / n;
-            for (int i = 0; i <= n; i++) xv[i] = xmin + i * dx;
-            return dx;
+            const double spacing = (last - first) / count;
+            points.resize(count + 1);
+            for (int k = 0; k <= count; ++k) points[k] = first + k * spacing;
+            return spacing;
         }
-        inline void logGrid(Array& xv, double xmin, double xmax, int n)
+        // count + 1 points from first to last, equidistant in the logarithm
+        inline void logGrid(Array& points, double first, double last, int count)
         {
-            xv.resize(n + 1);
-            double logxmin = log(xmin);
-            double dlogx = log(xmax / xmin) / n;
-            for (int i = 0; i <= n; i++) xv[i] = exp(logxmin + i * dlogx);
+            const double origin = log(first);
+            const double spacing = log(last / first) / count;
+            points.resize(count + 1);
+            for (int k = 0; k <= count; ++k) points[k] = exp(origin + k * spacing);
         }
-        inline double interpolateLinLin(double x, double x1, double x2, double f1, double f2)
+        // interpolation between (x1, f1) and (x2, f2): linear in both, logarithmic in x, logarithmic in both
+        inline double linLin(double x, double x1, double x2, double f1, double f2)
         {
-            return f1 + ((x - x1) / (x2 - x1)) * (f2 - f1);
+            const double fraction = (x - x1) / (x2 - x1);
+            return f1 + fraction * (f2 - f1);
         }
-        inline double interpolateLogLin(double x, double x1, double x2, double f1, double f2)
+        inline double logLin(double x, double x1, double x2, double f1, double f2)
         {
-            if (x1 <= 0 || x2 <= 0) return 0;
-            return f1 + log(x / x1) / log(x2 / x1) * (f2 - f1);
+            if (!(x1 > 0 && x2 > 0)) return 0;
+            const double fraction = log(x / x1) / log(x2 / x1);
+            return f1 + fraction * (f2 - f1);
         }
-        inline double interpolateLogLog(double x, double x1, double x2, double f1, double f2)
+        inline double logLog(double x, double x1, double x2, double f1, double f2)
         {
-            if (f1 <= 0 || f2 <= 0)
+            if (f1 > 0 && f2 > 0)
             {
-                if (x == x1) return f1;
-                if (x == x2) return f2;
-                return 0;
+                const double fraction = log(x / x1) / log(x2 / x1);
+                return f1 * exp(fraction * (log(f2 / f1)));
             }
-            return f1 * exp(log(x / x1) / log(x2 / x1) * (log(f2 / f1)));
+            // a vanishing end point: exact at the end points, zero in between
+            return x == x1 ? f1 : x == x2 ? f2 : 0;
         }
-        template<double F(double, double, double, double, double)>
-        inline double clampedValue(double x, const Array& xv, const Array& yv)
+        // value at x of the table (xs, ys) interpolated with Rule, held constant beyond its ends
+        template<double Rule(double, double, double, double, double)>
+        inline double clampedAt(double x, const Array& xs, const Array& ys)
         {
-            int n = static_cast<int>(xv.size());
-            int i = locate(xv, x);
-            if (i < 0) return yv[0];
-            if (i >= n - 1) return yv[n - 1];
-            return F(x, xv[i], xv[i + 1], yv[i], yv[i + 1]);
+            const int last = static_cast<int>(xs.size()) - 1;
+            const int i = bracket(xs, x);
+            if (i < 0) return ys[0];
+            if (i >= last) return ys[last];
+            return Rule(x, xs[i], xs[i + 1], ys[i], ys[i + 1]);
         }
-        template<double F(double, double, double, double, double)>
-        inline Array clampedResample(const Array& xresv, const Array& xoriv, const Array& yoriv)
+        template<double Rule(double, double, double, double, double)>
+        inline Array resampleClamped(const Array& targets, const Array& xs, const Array& ys)
         {
-            Array yresv(xresv.size());
-            for (size_t l = 0; l < xresv.size(); l++) yresv[l] = clampedValue<F>(xresv[l], xoriv, yoriv);
-            return yresv;
+            Array values(targets.size());
+            for (size_t k = 0; k != targets.size(); ++k) values[k] = clampedAt<Rule>(targets[k], xs, ys);
+            return values;
         }
     }
 
+    // ---- special functions (SKIRT/utils/SpecialFunctions.cpp:11-30,798-836)
     namespace special
     {
+        // ln Gamma(a) by the six-term Lanczos series
         inline double lngamma(double a)
         {
-            static const double cof[6] = {76.18009172947146,  -86.50532032941677,    24.01409824083091,
-                                          -1.231739572450155, 0.1208650973866179e-2, -0.5395239384953e-5};
-            double xx, y, tmp, ser;
-            y = xx = a;
-            tmp = xx + 5.5;
-            tmp -= (xx + 0.5) * log(tmp);
-            ser = 1.000000000190015;
-            for (int j = 0; j < 6; j++) ser += cof[j] / ++y;
-            return -tmp + log(2.5066282746310005 * ser / xx);
+            static const double lanczos[6] = {76.18009172947146,     -86.50532032941677,   24.01409824083091, -1.231739572450155,
+                                              0.1208650973866179e-2, -0.5395239384953e-5};
+            double shifted = a + 5.5;
+            shifted -= (a + 0.5) * log(shifted);
+            double series = 1.000000000190015;
+            double denominator = a;
+            for (double coefficient : lanczos) series += coefficient / ++denominator;
+            const double rootTwoPi = 2.5066282746310005;
+            return -shifted + log(rootTwoPi * series / a);
         }
         inline double gamma(double a) { return exp(lngamma(a)); }
+        // generalised logarithm (x^(1-p) - 1)/(1-p), continuous through p = 1
         inline double gln(double p, double x)
         {
             const double q = 1.0 - p;
             if (q == 0.0) return log(x);
-            if (fabs(q) < 1e-3)
-            {
-                double lnx = log(x);
-                double s = q * lnx;
-                return lnx * (1.0 + 0.5 * s + 1.0 / 6.0 * s * s + 1.0 / 24.0 * s * s * s);
-            }
-            return (pow(x, q) - 1.0) / q;
+            if (fabs(q) >= 1e-3) return (pow(x, q) - 1.0) / q;
+            const double logx = log(x);
+            const double t = q * logx;
+            return logx * (1.0 + 0.5 * t + 1.0 / 6.0 * t * t + 1.0 / 24.0 * t * t * t);
         }
+        // its inverse, the generalised exponential (1 + (1-p) x)^(1/(1-p))
         inline double gexp(double p, double x)
         {
             const double q = 1.0 - p;
             if (q == 0.0) return exp(x);
-            if (fabs(q) < 1e-3)
-            {
-                double x2 = x * x;
-                return exp(x)
-                       * (1.0 - 0.5 * x2 * q + 1.0 / 24.0 * x * x2 * (8.0 + 3.0 * x) * q * q
-                          - 1.0 / 48.0 * x2 * x2 * (12.0 + 8.0 * x + x2) * q * q * q);
-            }
-            return pow(1.0 + q * x, 1.0 / q);
+            if (fabs(q) >= 1e-3) return pow(1.0 + q * x, 1.0 / q);
+            const double xsq = x * x;
+            const double first = 0.5 * xsq * q;
+            const double second = 1.0 / 24.0 * x * xsq * (8.0 + 3.0 * x) * q * q;
+            const double third = 1.0 / 48.0 * xsq * xsq * (12.0 + 8.0 * x + xsq) * q * q * q;
+            return exp(x) * (1.0 - first + second - third);
         }
     }
 
-    namespace nr
+    namespace tab
     {
-        // NR::cdf2 (NR.cpp:25-54): builds the normalised cumulative distribution, normalises pv in place
-        inline double cdf2(bool loglog, const Array& xv, Array& pv, Array& Pv)
+        // cumulative distribution of the tabulated density (xs, density) with linear or power-law segments (NR.cpp:25-54):
+        // fills the normalised cumulative table, normalises the density in place, returns the norm
+        inline double cumulative(bool powerLaw, const Array& xs, Array& density, Array& cumul)
         {
-            size_t n = xv.size() - 1;
-            Pv.assign(n + 1, 0.);
-            for (size_t i = 0; i != n; ++i)
+            const size_t segments = xs.size() - 1;
+            cumul.assign(segments + 1, 0.);
+            for (size_t k = 0; k != segments; ++k)
             {
-                double area = 0.;
-                if (!loglog)
-                    area = 0.5 * (pv[i] + pv[i + 1]) * (xv[i + 1] - xv[i]);
-                else if (pv[i] > 0 && pv[i + 1] > 0)
+                const double left = density[k], right = density[k + 1];
+                double piece = 0.;
+                if (!powerLaw)
                 {
-                    double alpha = log(pv[i + 1] / pv[i]) / log(xv[i + 1] / xv[i]);
-                    area = pv[i] * xv[i] * special::gln(-alpha, xv[i + 1] / xv[i]);
+                    const double mean = 0.5 * (left + right);
+                    piece = mean * (xs[k + 1] - xs[k]);
                 }
-                Pv[i + 1] = Pv[i] + area;
+                else if (left > 0 && right > 0)
+                {
+                    const double ratio = xs[k + 1] / xs[k];
+                    const double slope = log(right / left) / log(ratio);
+                    piece = left * xs[k] * special::gln(-slope, ratio);
+                }
+                cumul[k + 1] = cumul[k] + piece;
             }
-            double norm = Pv[n];
+            const double norm = cumul[segments];
             if (norm > 0.)
             {
-                for (auto& p : pv) p /= norm;
-                for (auto& P : Pv) P /= norm;
+                for (double& value : density) value /= norm;
+                for (double& value : cumul) value /= norm;
             }
             return norm;
         }
@@ -239,43 +248,48 @@ namespace skh
         explicit Random(int seed = 0) { setSeed(seed); }
         void setSeed(int seed)
         {
-            std::seed_seq seedseq{979364188u + seed, 871244425u + seed, 1693909487u + seed, 1290454318u + seed,
-                                  210509498u + seed, 542237529u + seed, 3429911442u + seed, 3321294726u + seed};
-            _generator.seed(seedseq);
-            _seed = seed;
-            _draws = 0;
+            // the eight words the reference offsets by the seed (Random.cpp:40-46)
+            static const unsigned int words[8] = {979364188u, 871244425u, 1693909487u, 1290454318u,
+                                                  210509498u, 542237529u, 3429911442u, 3321294726u};
+            unsigned int keyed[8];
+            for (int k = 0; k != 8; ++k) keyed[k] = words[k] + seed;
+            std::seed_seq sequence(keyed, keyed + 8);
+            engine_.seed(sequence);
+            seed_ = seed;
+            drawn_ = 0;
         }
         double uniform()
         {
-            ++_draws;
-            return _distribution(_generator);
+            ++drawn_;
+            return unit_(engine_);
         }
         Vec3 position(const Box& box)
         {
-            double x = uniform();
-            double y = uniform();
-            double z = uniform();
-            return box.fracPos(x, y, z);
+            const double fx = uniform();
+            const double fy = uniform();
+            const double fz = uniform();
+            return box.fracPos(fx, fy, fz);
         }
-        // Random::direction() (Random.cpp:121-126) with Direction(theta, phi) (Direction.cpp:11-38)
+        // isotropic direction: polar angle from the first deviate, azimuth from the second (Random.cpp:121-126), as a
+        // unit vector with the poles snapped (Direction.cpp:11-38)
         Vec3 direction()
         {
-            double theta = acos(2.0 * uniform() - 1.0);
-            double phi = 2.0 * M_PI * uniform();
-            const double eps = 1e-8;
-            if (theta <= eps) return Vec3{0, 0, 1};
-            if (theta >= M_PI - eps) return Vec3{0, 0, -1};
-            double sintheta = sin(theta);
-            return Vec3{sintheta * cos(phi), sintheta * sin(phi), cos(theta)};
+            const double polar = acos(2.0 * uniform() - 1.0);
+            const double azimuth = 2.0 * M_PI * uniform();
+            const double snap = 1e-8;
+            if (polar <= snap) return Vec3{0, 0, 1};
+            if (polar >= M_PI - snap) return Vec3{0, 0, -1};
+            const double sine = sin(polar);
+            return Vec3{sine * cos(azimuth), sine * sin(azimuth), cos(polar)};
         }
-        int seed() const { return _seed; }
-        unsigned long long draws() const { return _draws; }
+        int seed() const { return seed_; }
+        unsigned long long draws() const { return drawn_; }
 
     private:
-        std::mt19937_64 _generator;
-        std::uniform_real_distribution<double> _distribution{std::nextafter(0., 1.), 1.};
-        int _seed{0};
-        unsigned long long _draws{0};
+        std::mt19937_64 engine_;
+        std::uniform_real_distribution<double> unit_{std::nextafter(0., 1.), 1.};
+        int seed_{0};
+        unsigned long long drawn_{0};
     };
 }
 

@@ -60,383 +60,404 @@ namespace skh
         return out("frequencysurfacebrightness", lambda * lambda * flambda / constants::c);
     }
 
-    // ================================================================ SersicFunction (SersicFunction.cpp:13-101)
-
-    SersicFunction::SersicFunction(double n)
-    {
-        if (n < 0.5 || n > 10.0) throw std::runtime_error("The Sersic parameter should be between 0.5 and 10");
-        double b = 2.0 * n - 1.0 / 3.0 + 4.0 / 405.0 / n + 46.0 / 25515.0 / (n * n) + 131.0 / 1148175.0 / (n * n * n);
-        double I0 = pow(b, 2.0 * n) / (M_PI * special::gamma(2.0 * n + 1));
-        int Ns = 101;
-        _sv.assign(Ns, 0.);
-        _Sv.assign(Ns, 0.);
-        _Mv.assign(Ns, 0.);
-        double logsmin = -6.0;
-        double logsmax = 4.0;
-        double dlogs = (logsmax - logsmin) / (Ns - 1.0);
-        for (int i = 0; i < Ns; i++)
-        {
-            double logs = logsmin + i * dlogs;
-            double s = pow(10.0, logs);
-            _sv[i] = s;
-            double alpha = b * pow(s, 1.0 / n);
-            double sum = 0.0;
-            int Nu = 10000;
-            double tmax = 100.0;
-            double umax = sqrt((tmax + 1.0) * (tmax - 1.0));
-            double du = umax / Nu;
-            for (int j = 0; j <= Nu; j++)
-            {
-                double weight = 1.0;
-                if (j == 0 || j == Nu) weight = 0.5;
-                double u = j * du;
-                double u2 = u * u;
-                double w;
-                if (u > 1e-3)
-                    w = (pow(1.0 + u2, 2.0 * n) - 1.0) / u2;
-                else
-                    w = 2.0 * n + n * (2.0 * n - 1.0) * u2 + 2.0 / 3.0 * n * (2.0 * n - 1.0) * (n - 1.0) * u2 * u2;
-                double integrandum = 2.0 * exp(-alpha * (1.0 + u2)) / sqrt(w);
-                sum += weight * integrandum;
-            }
-            _Sv[i] = I0 * pow(b, n) * pow(alpha, 1.0 - n) / M_PI * du * sum;
-        }
-        for (int i = 1; i < Ns; i++)
-        {
-            double sum = 0.0;
-            for (int j = 0; j <= 32; j++)
-            {
-                double weight = 1.0;
-                if (j == 0 || j == 32) weight = 0.5;
-                double ds = (_sv[i] - _sv[i - 1]) / 32.0;
-                double s = _sv[i - 1] + j * ds;
-                double S = operator()(s);
-                sum += weight * S * s * s * ds;
-            }
-            double dM = 4.0 * M_PI * sum;
-            _Mv[i] = _Mv[i - 1] + dM;
-        }
-        double last = _Mv[Ns - 1];
-        for (int i = 0; i < Ns; i++) _Mv[i] /= last;
-    }
-    double SersicFunction::operator()(double s) const { return nr::clampedValue<nr::interpolateLogLog>(s, _sv, _Sv); }
-    double SersicFunction::inverseMass(double M) const { return nr::clampedValue<nr::interpolateLogLog>(M, _Mv, _sv); }
-
-    // ================================================================ geometries
-
-    // UniformBoxGeometry.cpp:12-61
-    UniformBoxGeometry::UniformBoxGeometry(const Box& box) : _box(box)
-    {
-        if (box.xmax - box.xmin <= 0 || box.ymax - box.ymin <= 0 || box.zmax - box.zmin <= 0)
-            throw std::runtime_error("The extent of the box should be positive in every direction");
-        _rho = 1. / _box.volume();
-    }
-    double UniformBoxGeometry::density(Vec3 r) const { return _box.contains(r.x, r.y, r.z) ? _rho : 0.; }
-    double UniformBoxGeometry::SigmaX() const { return 1. / ((_box.ymax - _box.ymin) * (_box.zmax - _box.zmin)); }
-    double UniformBoxGeometry::SigmaY() const { return 1. / ((_box.xmax - _box.xmin) * (_box.zmax - _box.zmin)); }
-    double UniformBoxGeometry::SigmaZ() const { return 1. / ((_box.xmax - _box.xmin) * (_box.ymax - _box.ymin)); }
-
-    // ExpDiskGeometry.cpp:13-42,72-90
-    ExpDiskGeometry::ExpDiskGeometry(double hR, double hz, double Rmin, double Rmax, double zmax)
-        : _hR(hR), _hz(hz), _Rmin(Rmin), _Rmax(Rmax), _zmax(zmax)
-    {
-        if (_Rmin >= _Rmax && _Rmax > 0)
-            throw std::runtime_error("The radius of the central cavity should be smaller than the truncation radius");
-        double intphi = 2.0 * M_PI;
-        double intz = (_zmax > 0) ? -2.0 * _hz * expm1(-_zmax / _hz) : 2.0 * _hz;
-        double tmin = (_Rmin > 0) ? exp(-_Rmin / _hR) * (1.0 + _Rmin / _hR) : 1.0;
-        double tmax = (_Rmax > 0) ? exp(-_Rmax / _hR) * (1.0 + _Rmax / _hR) : 0.0;
-        double intR = _hR * _hR * (tmin - tmax);
-        _rho0 = 1.0 / (intR * intphi * intz);
-    }
-    double ExpDiskGeometry::density(Vec3 r) const
-    {
-        double R = sqrt(r.x * r.x + r.y * r.y);  // Position::cylRadius
-        double absz = fabs(r.z);
-        if (_Rmax > 0.0 && R > _Rmax) return 0.0;
-        if (_zmax > 0.0 && absz > _zmax) return 0.0;
-        if (R < _Rmin) return 0.0;
-        return _rho0 * exp(-R / _hR) * exp(-absz / _hz);
-    }
-    double ExpDiskGeometry::SigmaR() const
-    {
-        if (_Rmax > 0.0) return _rho0 * _hR * (exp(-_Rmin / _hR) - exp(-_Rmax / _hR));
-        return _rho0 * _hR * exp(-_Rmin / _hR);
-    }
-    double ExpDiskGeometry::SigmaZ() const
-    {
-        if (_Rmin > 0.0) return 0.0;
-        if (_zmax > 0.0) return -2.0 * _rho0 * _hz * expm1(-_zmax / _hz);
-        return 2.0 * _rho0 * _hz;
-    }
+    // ================================================================ shared pieces of the geometries
 
     namespace
     {
-        // SpecialFunctions::LambertW1 (SKIRT/utils/SpecialFunctions.cpp:578-625)
-        double lambertW1(double z)
+        double cylindricalRadius(Vec3 r) { return sqrt(r.x * r.x + r.y * r.y); }           // Position::cylRadius
+        double sphericalRadius(Vec3 r) { return sqrt(r.x * r.x + r.y * r.y + r.z * r.z); }  // Vec::norm
+        Vec3 alongDirection(double radius, Vec3 k) { return Vec3{radius * k.x, radius * k.y, radius * k.z}; }  // Position(r, bfk)
+        Vec3 fromCylinder(double R, double phi, double z) { return Vec3{R * cos(phi), R * sin(phi), z}; }
+
+        // composite trapezoid rule over the nodes 0..count with unit spacing: the end nodes weigh one half, the terms are
+        // accumulated in node order
+        template<class Term> double trapezoidSum(int count, Term term)
         {
-            const double eps = 1.0e-12;
-            const double em1 = 0.3678794411714423215955237701614608;
-            static const double c[12] = {-1.0,
-                                         2.331643981597124203363536062168,
-                                         -1.812187885639363490240191647568,
-                                         1.936631114492359755363277457668,
-                                         -2.353551201881614516821543561516,
-                                         3.066858901050631912893148922704,
-                                         -4.175335600258177138854984177460,
-                                         5.858023729874774148815053846119,
-                                         -8.401032217523977370984161688514,
-                                         12.250753501314460424,
-                                         -18.100697012472442755,
-                                         27.029044799010561650};
-            if (z < -em1 || z > 0.0 || std::isinf(z) || std::isnan(z)) throw std::runtime_error("LambertW1: bad argument");
-            if (z == 0.0) return -DBL_MAX;
-            double q = z + em1;
-            double r = -sqrt(q);
-            double t8 = c[8] + r * (c[9] + r * (c[10] + r * c[11]));
-            double t5 = c[5] + r * (c[6] + r * (c[7] + r * t8));
-            double t1 = c[1] + r * (c[2] + r * (c[3] + r * (c[4] + r * t5)));
-            double w0 = c[0] + r * t1;
-            if (q < 3.0e-3) return w0;
-            double w, e, p, t;
-            if (z < -1e-6)
-                w = w0;
-            else
+            double total = 0.0;
+            for (int node = 0; node <= count; ++node)
             {
-                double l1 = log(-z);
-                double l2 = log(-l1);
-                w = l1 - l2 + l2 / l1;
+                const double value = term(node);
+                total += (node == 0 || node == count) ? 0.5 * value : value;
             }
-            for (int i = 0; i < 10; i++)
+            return total;
+        }
+
+        // height drawn from a two-sided exponential of scale h (the vertical profile of the disk and of the ring)
+        double twoSidedExponential(double h, double X)
+        {
+            if (X <= 0.5) return h * log(2.0 * X);
+            return -h * log(2.0 * (1.0 - X));
+        }
+
+        // lower branch W_-1 of the Lambert function on [-1/e, 0] (SpecialFunctions.cpp:578-625): a series in
+        // sqrt(z + 1/e) evaluated by Horner's rule, refined by Halley iterations away from the branch point
+        double lambertLowerBranch(double z)
+        {
+            static const double inverseE = 0.3678794411714423215955237701614608;
+            static const double series[12] = {-1.0, 2.331643981597124203363536062168, -1.812187885639363490240191647568,
+                                              1.936631114492359755363277457668, -2.353551201881614516821543561516,
+                                              3.066858901050631912893148922704, -4.175335600258177138854984177460,
+                                              5.858023729874774148815053846119, -8.401032217523977370984161688514,
+                                              12.250753501314460424, -18.100697012472442755, 27.029044799010561650};
+            if (!(z >= -inverseE && z <= 0.0)) throw std::runtime_error("LambertW1: bad argument");
+            if (z == 0.0) return -DBL_MAX;
+            const double fromBranchPoint = z + inverseE;
+            const double root = -sqrt(fromBranchPoint);
+            double estimate = series[11];
+            for (int term = 10; term >= 0; --term) estimate = series[term] + root * estimate;
+            if (fromBranchPoint < 3.0e-3) return estimate;
+            double w = estimate;
+            if (!(z < -1e-6))
             {
-                e = exp(w);
-                t = w * e - z;
-                p = w + 1.0;
-                t /= e * p - 0.5 * (p + 1.0) * t / p;
-                w -= t;
-                if (fabs(t) < eps * (1.0 + fabs(w))) return w;
+                const double outer = log(-z);
+                const double inner = log(-outer);
+                w = outer - inner + inner / outer;
+            }
+            for (int round = 0; round < 10; ++round)
+            {
+                const double ew = exp(w);
+                const double next = w + 1.0;
+                double correction = w * ew - z;
+                correction /= ew * next - 0.5 * (next + 1.0) * correction / next;
+                w -= correction;
+                if (fabs(correction) < 1.0e-12 * (1.0 + fabs(w))) return w;
             }
             throw std::runtime_error("LambertW1: no convergence");
         }
     }
-    Vec3 ExpDiskGeometry::generatePosition(Random& random) const
+
+    // ================================================================ SersicProfile (SersicFunction.cpp:13-101)
+
+    double SersicProfile::shapeB(double index)
     {
-        double R, X;
-        do
+        const double n2 = index * index;
+        double b = 2.0 * index - 1.0 / 3.0;
+        b = b + 4.0 / 405.0 / index;
+        b = b + 46.0 / 25515.0 / n2;
+        b = b + 131.0 / 1148175.0 / (n2 * index);
+        return b;
+    }
+
+    // Abel deprojection of the Sersic surface brightness at radius s (in effective radii): the substitution t^2 = 1 + u^2
+    // on the line of sight, 10^4 trapezoid intervals up to t = 100
+    double SersicProfile::deproject(double index, double b, double central, double s) const
+    {
+        const int intervals = 10000;
+        const double lastT = 100.0;
+        const double lastU = sqrt((lastT + 1.0) * (lastT - 1.0));
+        const double spacing = lastU / intervals;
+        const double twice = 2.0 * index;
+        const double depth = b * pow(s, 1.0 / index);
+        const double lineOfSight = trapezoidSum(intervals, [&](int node) {
+            const double u = node * spacing;
+            const double usq = u * u;
+            double jacobian;
+            if (u > 1e-3)
+                jacobian = (pow(1.0 + usq, twice) - 1.0) / usq;
+            else
+            {
+                const double odd = twice - 1.0;
+                jacobian = twice + index * odd * usq + 2.0 / 3.0 * index * odd * (index - 1.0) * usq * usq;
+            }
+            return 2.0 * exp(-depth * (1.0 + usq)) / sqrt(jacobian);
+        });
+        return central * pow(b, index) * pow(depth, 1.0 - index) / M_PI * spacing * lineOfSight;
+    }
+
+    SersicProfile::SersicProfile(double index)
+    {
+        if (index < 0.5 || index > 10.0) throw std::runtime_error("The Sersic parameter should be between 0.5 and 10");
+        const double b = shapeB(index);
+        const double central = pow(b, 2.0 * index) / (M_PI * special::gamma(2.0 * index + 1));
+        // 101 radii, ten per decade from 10^-6 to 10^4 effective radii
+        const int count = 101;
+        const double firstDecade = -6.0, lastDecade = 4.0;
+        const double decadeStep = (lastDecade - firstDecade) / (count - 1.0);
+        radius_.assign(count, 0.);
+        profile_.assign(count, 0.);
+        mass_.assign(count, 0.);
+        for (int i = 0; i < count; ++i)
         {
-            X = random.uniform();
-            R = _hR * (-1.0 - lambertW1((X - 1.0) / M_E));
-        } while ((_Rmax > 0.0 && R >= _Rmax) || R <= _Rmin);
-        double phi = 2.0 * M_PI * random.uniform();
+            radius_[i] = pow(10.0, firstDecade + i * decadeStep);
+            profile_[i] = deproject(index, b, central, radius_[i]);
+        }
+        // mass within each radius: 32 trapezoid intervals per table interval, on the interpolated profile
+        const int pieces = 32;
+        for (int i = 1; i < count; ++i)
+        {
+            const double inner = radius_[i - 1];
+            const double piece = (radius_[i] - inner) / 32.0;
+            const double shell = trapezoidSum(pieces, [&](int node) {
+                const double s = inner + node * piece;
+                return value(s) * s * s * piece;
+            });
+            mass_[i] = mass_[i - 1] + 4.0 * M_PI * shell;
+        }
+        const double total = mass_[count - 1];
+        for (double& m : mass_) m /= total;
+    }
+    double SersicProfile::value(double s) const { return tab::clampedAt<tab::logLog>(s, radius_, profile_); }
+    double SersicProfile::radiusOfMass(double M) const { return tab::clampedAt<tab::logLog>(M, mass_, radius_); }
+
+    // ================================================================ geometries
+
+    // UniformBoxGeometry.cpp:12-61
+    UniformBoxGeometry::UniformBoxGeometry(const Box& box) : bounds_(box)
+    {
+        const bool empty = box.xmax - box.xmin <= 0 || box.ymax - box.ymin <= 0 || box.zmax - box.zmin <= 0;
+        if (empty) throw std::runtime_error("The extent of the box should be positive in every direction");
+        level_ = 1. / bounds_.volume();
+    }
+    double UniformBoxGeometry::density(Vec3 r) const { return bounds_.contains(r.x, r.y, r.z) ? level_ : 0.; }
+    double UniformBoxGeometry::columnX() const { return 1. / ((bounds_.ymax - bounds_.ymin) * (bounds_.zmax - bounds_.zmin)); }
+    double UniformBoxGeometry::columnY() const { return 1. / ((bounds_.xmax - bounds_.xmin) * (bounds_.zmax - bounds_.zmin)); }
+    double UniformBoxGeometry::columnZ() const { return 1. / ((bounds_.xmax - bounds_.xmin) * (bounds_.ymax - bounds_.ymin)); }
+
+    // ExpDiskGeometry.cpp:13-90
+    ExpDiskGeometry::ExpDiskGeometry(double radialScale, double verticalScale, double innerRadius, double outerRadius, double maxHeight)
+        : scaleR_(radialScale), scaleZ_(verticalScale), innerR_(innerRadius), outerR_(outerRadius), maxZ_(maxHeight)
+    {
+        if (outerR_ > 0 && innerR_ >= outerR_)
+            throw std::runtime_error("The radius of the central cavity should be smaller than the truncation radius");
+        // the density integrates to one: azimuth x height x radius
+        const double azimuth = 2.0 * M_PI;
+        const double height = maxZ_ > 0 ? -2.0 * scaleZ_ * expm1(-maxZ_ / scaleZ_) : 2.0 * scaleZ_;
+        auto radialPrimitive = [this](double R) { return exp(-R / scaleR_) * (1.0 + R / scaleR_); };
+        const double fromInner = innerR_ > 0 ? radialPrimitive(innerR_) : 1.0;
+        const double fromOuter = outerR_ > 0 ? radialPrimitive(outerR_) : 0.0;
+        const double radius = scaleR_ * scaleR_ * (fromInner - fromOuter);
+        central_ = 1.0 / (radius * azimuth * height);
+    }
+    double ExpDiskGeometry::density(Vec3 r) const
+    {
+        const double R = cylindricalRadius(r);
+        const double height = fabs(r.z);
+        const bool outside = (outerR_ > 0.0 && R > outerR_) || (maxZ_ > 0.0 && height > maxZ_) || R < innerR_;
+        if (outside) return 0.0;
+        return central_ * exp(-R / scaleR_) * exp(-height / scaleZ_);
+    }
+    double ExpDiskGeometry::radialColumn() const
+    {
+        const double atInner = exp(-innerR_ / scaleR_);
+        if (outerR_ > 0.0) return central_ * scaleR_ * (atInner - exp(-outerR_ / scaleR_));
+        return central_ * scaleR_ * atInner;
+    }
+    double ExpDiskGeometry::columnZ() const
+    {
+        if (innerR_ > 0.0) return 0.0;  // the axis runs through the cavity
+        if (maxZ_ > 0.0) return -2.0 * central_ * scaleZ_ * expm1(-maxZ_ / scaleZ_);
+        return 2.0 * central_ * scaleZ_;
+    }
+    Vec3 ExpDiskGeometry::samplePosition(Random& random) const
+    {
+        // radius: inversion of 1 - (1 + R/h) exp(-R/h) through the Lambert function, rejection on cavity and truncation
+        double R;
+        while (true)
+        {
+            const double X = random.uniform();
+            R = scaleR_ * (-1.0 - lambertLowerBranch((X - 1.0) / M_E));
+            const bool rejected = (outerR_ > 0.0 && R >= outerR_) || R <= innerR_;
+            if (!rejected) break;
+        }
+        const double phi = 2.0 * M_PI * random.uniform();
         double z;
         do
-        {
-            X = random.uniform();
-            z = (X <= 0.5) ? _hz * log(2.0 * X) : -_hz * log(2.0 * (1.0 - X));
-        } while (_zmax > 0.0 && fabs(z) >= _zmax);
-        return Vec3{R * cos(phi), R * sin(phi), z};  // Position(R, phi, z, CYLINDRICAL)
+            z = twoSidedExponential(scaleZ_, random.uniform());
+        while (maxZ_ > 0.0 && fabs(z) >= maxZ_);
+        return fromCylinder(R, phi, z);
     }
 
     // SersicGeometry.cpp:21-52
-    SersicGeometry::SersicGeometry(double reff, double n) : _reff(reff), _n(n)
+    SersicGeometry::SersicGeometry(double effectiveRadius, double index) : reff_(effectiveRadius), index_(index)
     {
-        _rho0 = 1.0 / (_reff * _reff * _reff);
-        _b = 2.0 * _n - 1.0 / 3.0 + 4.0 / 405.0 / _n + 46.0 / 25515.0 / (_n * _n) + 131.0 / 1148175.0 / (_n * _n * _n);
-        _function = std::make_unique<SersicFunction>(_n);
+        central_ = 1.0 / (reff_ * reff_ * reff_);
+        b_ = SersicProfile::shapeB(index_);
+        profile_ = std::make_unique<SersicProfile>(index_);
     }
-    double SersicGeometry::density(Vec3 r) const
+    double SersicGeometry::density(Vec3 r) const { return central_ * profile_->value(sphericalRadius(r) / reff_); }
+    double SersicGeometry::radialColumn() const
     {
-        double radius = sqrt(r.x * r.x + r.y * r.y + r.z * r.z);  // Vec::norm
-        double s = radius / _reff;
-        return _rho0 * (*_function)(s);
+        const double twice = 2.0 * index_;
+        return 1.0 / (reff_ * reff_) * pow(b_, twice) / (2.0 * M_PI * special::gamma(twice + 1.0));
     }
-    double SersicGeometry::Sigmar() const
+    Vec3 SersicGeometry::samplePosition(Random& random) const
     {
-        return 1.0 / (_reff * _reff) * pow(_b, 2.0 * _n) / (2.0 * M_PI * special::gamma(2.0 * _n + 1.0));
-    }
-
-    Vec3 SersicGeometry::generatePosition(Random& random) const
-    {
-        double r = _reff * _function->inverseMass(random.uniform());  // SersicGeometry::randomRadius
-        Vec3 k = random.direction();
-        return Vec3{r * k.x, r * k.y, r * k.z};  // Position(r, bfk)
+        const double radius = reff_ * profile_->radiusOfMass(random.uniform());  // SersicGeometry::randomRadius
+        return alongDirection(radius, random.direction());
     }
 
     // PlummerGeometry.cpp:12-38
-    PlummerGeometry::PlummerGeometry(double c) : _c(c) { _rho0 = 0.75 / pow(_c, 3) / M_PI; }
+    PlummerGeometry::PlummerGeometry(double scale) : scale_(scale) { central_ = 0.75 / pow(scale_, 3) / M_PI; }
     double PlummerGeometry::density(Vec3 r) const
     {
-        double radius = sqrt(r.x * r.x + r.y * r.y + r.z * r.z);
-        double s = radius / _c;
-        return _rho0 * pow(1.0 + s * s, -2.5);
+        const double s = sphericalRadius(r) / scale_;
+        return central_ * pow(1.0 + s * s, -2.5);
     }
-    double PlummerGeometry::Sigmar() const { return 0.5 / (M_PI * _c * _c); }
-    Vec3 PlummerGeometry::generatePosition(Random& random) const
+    double PlummerGeometry::radialColumn() const { return 0.5 / (M_PI * scale_ * scale_); }
+    Vec3 PlummerGeometry::samplePosition(Random& random) const
     {
-        double t = pow(random.uniform(), 1.0 / 3.0);
-        double r = _c * t / sqrt((1.0 - t) * (1.0 + t));
-        Vec3 k = random.direction();
-        return Vec3{r * k.x, r * k.y, r * k.z};
+        const double t = pow(random.uniform(), 1.0 / 3.0);
+        const double radius = scale_ * t / sqrt((1.0 - t) * (1.0 + t));
+        return alongDirection(radius, random.direction());
     }
 
     // ================================================================ SpheroidalGeometryDecorator
 
-    double SpheroidalGeometry::density(Vec3 bfr) const
+    double SpheroidalGeometry::density(Vec3 r) const
     {
-        // AxGeometry::density(Position) passes (cylindrical radius, height); the spherical density is evaluated at radius
-        // m (a position (m, 0, 0): sqrt(m*m) == m in IEEE arithmetic)
-        double R = sqrt(bfr.x * bfr.x + bfr.y * bfr.y), z = bfr.z;
-        double m = sqrt(R * R + z * z / (_q * _q));
-        return 1.0 / _q * _inner->density(Vec3{m, 0., 0.});
+        // the spherical density at the spheroidal radius (AxGeometry::density passes cylindrical radius and height; a
+        // position (m, 0, 0) has norm m exactly)
+        const double R = cylindricalRadius(r);
+        const double m = sqrt(R * R + r.z * r.z / (flat_ * flat_));
+        return 1.0 / flat_ * sphere_->density(Vec3{m, 0., 0.});
     }
-    Vec3 SpheroidalGeometry::generatePosition(Random& random) const
+    Vec3 SpheroidalGeometry::samplePosition(Random& random) const
     {
-        Vec3 s = _inner->generatePosition(random);
-        return Vec3{s.x, s.y, _q * s.z};
+        const Vec3 p = sphere_->samplePosition(random);
+        return Vec3{p.x, p.y, flat_ * p.z};
     }
 
     // ================================================================ ShellGeometry, TorusGeometry, RingGeometry
 
-    namespace
+    void PowerLawRadius::prepare(double rmin, double rmax, double p)
     {
-        // SpecialFunctions::gln2 (SpecialFunctions.cpp:815-818)
-        double gln2(double p, double x1, double x2) { return pow(x2, 1.0 - p) * special::gln(p, x1 / x2); }
+        inner = rmin, outer = rmax, exponent = p;
+        // generalised logarithms of exponent p - 2 (SpecialFunctions::gln, gln2): the cumulative radial distribution
+        logInner = special::gln(p - 2.0, rmin);
+        logSpan = pow(rmin, 1.0 - (p - 2.0)) * special::gln(p - 2.0, rmax / rmin);
+        powInner = pow(rmin, 3.0 - p);
+        powOuter = pow(rmax, 3.0 - p);
+    }
+    double PowerLawRadius::sample(double X) const
+    {
+        if (fabs(exponent - 3.0) < 1e-2) return special::gexp(exponent - 2.0, logInner + X * logSpan);
+        return pow((1.0 - X) * powInner + X * powOuter, 1.0 / (3.0 - exponent));
+    }
+    double PowerLawRadius::column(double amplitude) const
+    {
+        return amplitude * (pow(inner, 1.0 - exponent) * special::gln(exponent, outer / inner));
     }
 
-    ShellGeometry::ShellGeometry(double rmin, double rmax, double p) : _rmin(rmin), _rmax(rmax), _p(p)
+    ShellGeometry::ShellGeometry(double rmin, double rmax, double p)
     {
-        if (_rmax <= _rmin) throw std::runtime_error("the outer radius of the shell should be larger than the inner radius");
-        _smin = special::gln(_p - 2.0, _rmin);
-        _sdiff = gln2(_p - 2.0, _rmax, _rmin);
-        _tmin = pow(_rmin, 3.0 - _p);
-        _tmax = pow(_rmax, 3.0 - _p);
-        _A = 0.25 / M_PI / _sdiff;
+        if (rmax <= rmin) throw std::runtime_error("the outer radius of the shell should be larger than the inner radius");
+        radial_.prepare(rmin, rmax, p);
+        amplitude_ = 0.25 / M_PI / radial_.logSpan;
     }
-    double ShellGeometry::density(Vec3 bfr) const
+    double ShellGeometry::density(Vec3 r) const
     {
-        double r = sqrt(bfr.x * bfr.x + bfr.y * bfr.y + bfr.z * bfr.z);
-        if (r < _rmin || r > _rmax) return 0.0;
-        return _A * pow(r, -_p);
+        const double radius = sphericalRadius(r);
+        if (radius < radial_.inner || radius > radial_.outer) return 0.0;
+        return amplitude_ * pow(radius, -radial_.exponent);
     }
-    double ShellGeometry::Sigmar() const { return _A * gln2(_p, _rmax, _rmin); }
-    Vec3 ShellGeometry::generatePosition(Random& random) const
+    Vec3 ShellGeometry::samplePosition(Random& random) const
     {
-        double X = random.uniform();
-        double r;
-        if (fabs(_p - 3.0) < 1e-2)
-            r = special::gexp(_p - 2.0, _smin + X * _sdiff);
-        else
-            r = pow((1.0 - X) * _tmin + X * _tmax, 1.0 / (3.0 - _p));
-        Vec3 k = random.direction();
-        return Vec3{r * k.x, r * k.y, r * k.z};
+        const double radius = radial_.sample(random.uniform());
+        return alongDirection(radius, random.direction());
     }
 
-    TorusGeometry::TorusGeometry(double p, double q, double Delta, double rmin, double rmax, bool rani, double rcut)
-        : _p(p), _q(q), _Delta(Delta), _rmin(rmin), _rmax(rmax), _rani(rani), _rcut(rcut)
+    TorusGeometry::TorusGeometry(double p, double q, double halfOpening, double rmin, double rmax, bool anisotropicInner,
+                                 double cutoffRadius)
+        : polar_(q), cutoff_(cutoffRadius), anisotropic_(anisotropicInner)
     {
-        _sinDelta = sin(_Delta);
-        _smin = special::gln(_p - 2.0, _rmin);
-        _sdiff = gln2(_p - 2.0, _rmax, _rmin);
-        _tmin = pow(_rmin, 3.0 - _p);
-        _tmax = pow(_rmax, 3.0 - _p);
-        if (_q > 1e-3)
-            _A = _q * 0.25 / M_PI / _sdiff / (1.0 - exp(-_q * _sinDelta));
+        sinOpening_ = sin(halfOpening);
+        radial_.prepare(rmin, rmax, p);
+        if (polar_ > 1e-3)
+            amplitude_ = polar_ * 0.25 / M_PI / radial_.logSpan / (1.0 - exp(-polar_ * sinOpening_));
         else
-            _A = 0.25 / M_PI / _sdiff / _sinDelta;
+            amplitude_ = 0.25 / M_PI / radial_.logSpan / sinOpening_;
     }
-    double TorusGeometry::density(Vec3 bfr) const
+    double TorusGeometry::density(Vec3 position) const
     {
-        // AxGeometry::density(Position) passes the cylindrical radius and the height (AxGeometry.cpp:11-17)
-        double R = sqrt(bfr.x * bfr.x + bfr.y * bfr.y), z = bfr.z;
-        double r = sqrt(R * R + z * z);
-        double costheta = z / r;
-        if (r >= _rmax) return 0.0;
-        if (_rani)
+        // (AxGeometry::density passes the cylindrical radius and the height, AxGeometry.cpp:11-17)
+        const double R = cylindricalRadius(position), z = position.z;
+        const double radius = sqrt(R * R + z * z);
+        const double slope = fabs(z / radius);  // |cos theta|
+        if (radius >= radial_.outer) return 0.0;
+        if (anisotropic_)
         {
-            double rminani = _rmin * sqrt(6. / 7. * fabs(costheta) * (2. * fabs(costheta) + 1));
-            if (r <= rminani || r < _rcut) return 0.0;
+            // inner wall that recedes towards the equator, and the sublimation cutoff
+            const double wall = radial_.inner * sqrt(6. / 7. * slope * (2. * slope + 1));
+            if (radius <= wall || radius < cutoff_) return 0.0;
         }
-        else
-        {
-            if (r <= _rmin) return 0.0;
-        }
-        if (fabs(costheta) >= _sinDelta) return 0.0;
-        return _A * pow(r, -_p) * exp(-_q * fabs(costheta));
+        else if (radius <= radial_.inner)
+            return 0.0;
+        if (slope >= sinOpening_) return 0.0;
+        return amplitude_ * pow(radius, -radial_.exponent) * exp(-polar_ * slope);
     }
-    double TorusGeometry::SigmaR() const { return _A * gln2(_p, _rmax, _rmin); }
-    Vec3 TorusGeometry::generatePosition(Random& random) const
+    Vec3 TorusGeometry::samplePosition(Random& random) const
     {
+        // radius, polar angle and azimuth from their marginal distributions; rejection against the anisotropic wall
         while (true)
         {
-            double X = random.uniform();
-            double r;
-            if (fabs(_p - 3.0) < 1e-2)
-                r = special::gexp(_p - 2.0, _smin + X * _sdiff);
-            else
-                r = pow((1.0 - X) * _tmin + X * _tmax, 1.0 / (3.0 - _p));
-            X = random.uniform();
-            double costheta;
-            if (_q < 1e-3)
-                costheta = (1.0 - 2.0 * X) * _sinDelta;
+            const double radius = radial_.sample(random.uniform());
+            const double X = random.uniform();
+            double cosine;
+            if (polar_ < 1e-3)
+                cosine = (1.0 - 2.0 * X) * sinOpening_;
             else
             {
-                double B = 1.0 - exp(-_q * _sinDelta);
-                costheta = (X < 0.5) ? -log(1.0 - B * (1.0 - 2.0 * X)) / _q : log(1.0 - B * (2.0 * X - 1.0)) / _q;
+                const double span = 1.0 - exp(-polar_ * sinOpening_);
+                if (X < 0.5)
+                    cosine = -log(1.0 - span * (1.0 - 2.0 * X)) / polar_;
+                else
+                    cosine = log(1.0 - span * (2.0 * X - 1.0)) / polar_;
             }
-            double theta = acos(costheta);
-            double phi = 2.0 * M_PI * random.uniform();
-            // Position(r, theta, phi, SPHERICAL) (Vec/Position.cpp)
-            double sintheta = sin(theta);
-            Vec3 pos{r * sintheta * cos(phi), r * sintheta * sin(phi), r * cos(theta)};
-            if (density(pos)) return pos;
+            const double polarAngle = acos(cosine);
+            const double phi = 2.0 * M_PI * random.uniform();
+            const double sine = sin(polarAngle);  // Position(r, theta, phi, SPHERICAL)
+            const Vec3 candidate{radius * sine * cos(phi), radius * sine * sin(phi), radius * cos(polarAngle)};
+            if (density(candidate)) return candidate;
         }
     }
 
-    RingGeometry::RingGeometry(double R0, double w, double hz) : _R0(R0), _w(w), _hz(hz)
+    RingGeometry::RingGeometry(double ringRadius, double width, double verticalScale)
+        : centre_(ringRadius), width_(width), scaleZ_(verticalScale)
     {
-        double t = _R0 / _w / M_SQRT2;
-        double intz = 2.0 * _hz;
-        double intR = _w * _w * (exp(-t * t) + sqrt(M_PI) * t * (1.0 + erf(t)));
-        _A = 1.0 / (2.0 * M_PI * intz * intR);
-        int NR = 330;
-        nr::linearGrid(_Rv, std::max(0., _R0 - 8 * _w), _R0 + 8 * _w, NR - 1);
-        _Xv.resize(NR);
-        double sqrtpi = sqrt(M_PI);
-        for (int i = 0; i < NR; i++)
+        const double rootPi = sqrt(M_PI);
+        const double t = centre_ / width_ / M_SQRT2;
+        const double gaussAtAxis = exp(-t * t);
+        const double errAtAxis = erf(t);
+        const double height = 2.0 * scaleZ_;
+        const double radial = width_ * width_ * (gaussAtAxis + rootPi * t * (1.0 + errAtAxis));
+        amplitude_ = 1.0 / (2.0 * M_PI * height * radial);
+        // cumulative radial distribution on 330 radii within eight widths of the ring
+        const int count = 330;
+        tab::linearGrid(tableR_, std::max(0., centre_ - 8 * width_), centre_ + 8 * width_, count - 1);
+        tableCdf_.assign(count, 0.);
+        const double scale = 4.0 * M_PI * amplitude_ * scaleZ_ * width_ * width_;
+        for (int i = 0; i < count; ++i)
         {
-            double R = _Rv[i];
-            double u = (_R0 - R) / _w / M_SQRT2;
-            _Xv[i] = 4.0 * M_PI * _A * _hz * _w * _w * (exp(-t * t) - exp(-u * u) + sqrtpi * t * (erf(t) - erf(u)));
+            const double u = (centre_ - tableR_[i]) / width_ / M_SQRT2;
+            tableCdf_[i] = scale * (gaussAtAxis - exp(-u * u) + rootPi * t * (errAtAxis - erf(u)));
         }
-        _Xv[0] = 0.0;
-        _Xv[NR - 1] = 1.0;
+        tableCdf_.front() = 0.0;
+        tableCdf_.back() = 1.0;
     }
-    double RingGeometry::density(Vec3 bfr) const
+    double RingGeometry::density(Vec3 r) const
     {
-        double R = sqrt(bfr.x * bfr.x + bfr.y * bfr.y), z = bfr.z;
-        double u = (R - _R0) / (M_SQRT2 * _w);
-        return _A * exp(-u * u) * exp(-fabs(z) / _hz);
+        const double u = (cylindricalRadius(r) - centre_) / (M_SQRT2 * width_);
+        return amplitude_ * exp(-u * u) * exp(-fabs(r.z) / scaleZ_);
     }
-    double RingGeometry::SigmaR() const
+    double RingGeometry::radialColumn() const
     {
-        double t = _R0 / (M_SQRT2 * _w);
-        return sqrt(M_PI / 2.0) * _A * _w * (1.0 + erf(t));
+        const double t = centre_ / (M_SQRT2 * width_);
+        return sqrt(M_PI / 2.0) * amplitude_ * width_ * (1.0 + erf(t));
     }
-    double RingGeometry::SigmaZ() const
+    double RingGeometry::columnZ() const
     {
-        double t = _R0 / (M_SQRT2 * _w);
-        return 2.0 * _A * _hz * exp(-t * t);
+        const double t = centre_ / (M_SQRT2 * width_);
+        return 2.0 * amplitude_ * scaleZ_ * exp(-t * t);
     }
-    Vec3 RingGeometry::generatePosition(Random& random) const
+    Vec3 RingGeometry::samplePosition(Random& random) const
     {
-        // Random::cdfLinLin (Random.cpp:190-195) on the tabulated radial distribution, then phi, then z
-        double X = random.uniform();
-        int i = nr::locateClip(_Xv, X);
-        double R = nr::interpolateLinLin(X, _Xv[i], _Xv[i + 1], _Rv[i], _Rv[i + 1]);
-        double phi = 2.0 * M_PI * random.uniform();
-        X = random.uniform();
-        double z = (X <= 0.5) ? _hz * log(2.0 * X) : -_hz * log(2.0 * (1.0 - X));
-        return Vec3{R * cos(phi), R * sin(phi), z};
+        // Random::cdfLinLin (Random.cpp:190-195) on the tabulated radial distribution, then azimuth, then height
+        const double X = random.uniform();
+        const int i = tab::bracketClipped(tableCdf_, X);
+        const double R = tab::linLin(X, tableCdf_[i], tableCdf_[i + 1], tableR_[i], tableR_[i + 1]);
+        const double phi = 2.0 * M_PI * random.uniform();
+        const double z = twoSidedExponential(scaleZ_, random.uniform());
+        return fromCylinder(R, phi, z);
     }
 
     // ================================================================ DustMix (DustMix.cpp:47-162)
@@ -463,7 +484,7 @@ namespace skh
         bool radioCutoff = wavelengths.back() > dm;
         if (radioCutoff)
         {
-            wavelengths.resize(nr::locate(wavelengths, dm) + 1);
+            wavelengths.resize(tab::bracket(wavelengths, dm) + 1);
             if (wavelengths.empty() || wavelengths.back() != dm) wavelengths.push_back(dm);
             wavelengths.push_back(dm * 1.001);
         }
@@ -490,9 +511,9 @@ namespace skh
             insigmaabs[i] = mu * ink[i] * (1. - ina[i]);
             insigmasca[i] = mu * ink[i] * ina[i];
         }
-        sigmaAbs = nr::clampedResample<nr::interpolateLogLog>(lambdaSample, inl, insigmaabs);
-        sigmaSca = nr::clampedResample<nr::interpolateLogLog>(lambdaSample, inl, insigmasca);
-        asymmpar = nr::clampedResample<nr::interpolateLogLin>(lambdaSample, inl, ing);
+        sigmaAbs = tab::resampleClamped<tab::logLog>(lambdaSample, inl, insigmaabs);
+        sigmaSca = tab::resampleClamped<tab::logLog>(lambdaSample, inl, insigmasca);
+        asymmpar = tab::resampleClamped<tab::logLin>(lambdaSample, inl, ing);
 
         // clamp g (DustMix.cpp:139-146), derive extinction (:160-162)
         const double gmax = 0.999999;
@@ -515,7 +536,7 @@ namespace skh
         if (normType == "OpticalDepthMaterialNormalization")
         {
             // AxisMaterialNormalization.cpp:11-25, OpticalDepthMaterialNormalization.cpp:13-27
-            double geomColumnDensity = normAxis == 'X' ? geometry->SigmaX() : normAxis == 'Y' ? geometry->SigmaY() : geometry->SigmaZ();
+            double geomColumnDensity = normAxis == 'X' ? geometry->columnX() : normAxis == 'Y' ? geometry->columnY() : geometry->columnZ();
             if (geomColumnDensity <= 0.)
                 throw std::runtime_error("Can't normalize material for geometry with zero column density along selected axis");
             double section = mix->sectionExt(normWavelength);
@@ -558,7 +579,7 @@ namespace skh
             {
                 // NR::buildPowerLawGrid
                 if (fabs(spec.ratio - 1.) < 1e-3)
-                    nr::linearGrid(tv, 0.0, 1.0, n);
+                    tab::linearGrid(tv, 0.0, 1.0, n);
                 else
                 {
                     tv.resize(n + 1);
@@ -572,7 +593,7 @@ namespace skh
             {
                 // NR::buildSymmetricPowerLawGrid
                 if (fabs(spec.ratio - 1.) < 1e-3)
-                    nr::linearGrid(tv, 0.0, 1.0, n);
+                    tab::linearGrid(tv, 0.0, 1.0, n);
                 else
                 {
                     tv.resize(n + 1);
@@ -630,7 +651,7 @@ namespace skh
                 tv[k++] = 1.;
             }
             else
-                nr::linearGrid(tv, 0.0, 1.0, (spec.type == "PowMesh" || spec.type == "LogMesh") ? 1 : n);
+                tab::linearGrid(tv, 0.0, 1.0, (spec.type == "PowMesh" || spec.type == "LogMesh") ? 1 : n);
             return tv;
         };
         const MeshSpec* specs = meshSpec;

@@ -42,31 +42,36 @@ namespace skh
 
     // ---------------------------------------------------------------- geometries
 
+    // A normalised density distribution: value, column densities along the coordinate axes through the origin (what the
+    // material normalisations need), and random positions drawn from it.  Every class evaluates its formulas in the
+    // operation order of the SKIRT class it stands for, so that setup-time tables come out bit-identical.
     class Geometry
     {
     public:
         virtual ~Geometry() {}
         virtual std::string type() const = 0;
         virtual double density(Vec3 r) const = 0;
-        virtual double SigmaX() const = 0;
-        virtual double SigmaY() const = 0;
-        virtual double SigmaZ() const = 0;
-        // Geometry::generatePosition: a random position drawn from the density (consumes the simulation's random stream)
-        virtual Vec3 generatePosition(Random& random) const = 0;
+        virtual double columnX() const = 0;
+        virtual double columnY() const = 0;
+        virtual double columnZ() const = 0;
+        // a random position drawn from the density; consumes the simulation's random stream in the reference's order
+        virtual Vec3 samplePosition(Random& random) const = 0;
     };
 
-    // SKIRT/utils/SersicFunction.cpp:13-101
-    class SersicFunction
+    // deprojected Sersic profile and its cumulative mass, tabulated on 101 logarithmic radii (SersicFunction.cpp:13-101)
+    class SersicProfile
     {
     public:
-        explicit SersicFunction(double n);
-        double operator()(double s) const;
-        double inverseMass(double M) const;
-        const Array& sv() const { return _sv; }
-        const Array& Mv() const { return _Mv; }
+        explicit SersicProfile(double index);
+        double value(double s) const;          // S(s)
+        double radiusOfMass(double M) const;   // inverse of the cumulative mass
+        const Array& radii() const { return radius_; }
+        const Array& masses() const { return mass_; }
+        static double shapeB(double index);    // the b(n) series of the Sersic law
 
     private:
-        Array _sv, _Sv, _Mv;
+        double deproject(double index, double b, double central, double s) const;
+        Array radius_, profile_, mass_;
     };
 
     class UniformBoxGeometry : public Geometry
@@ -75,111 +80,123 @@ namespace skh
         explicit UniformBoxGeometry(const Box& box);
         std::string type() const override { return "UniformBoxGeometry"; }
         double density(Vec3 r) const override;
-        double SigmaX() const override;
-        double SigmaY() const override;
-        double SigmaZ() const override;
-        Vec3 generatePosition(Random& random) const override { return random.position(_box); }  // UniformBoxGeometry.cpp:37-40
-        const Box& box() const { return _box; }
+        double columnX() const override;
+        double columnY() const override;
+        double columnZ() const override;
+        Vec3 samplePosition(Random& random) const override { return random.position(bounds_); }  // UniformBoxGeometry.cpp:37-40
+        const Box& box() const { return bounds_; }
 
     private:
-        Box _box;
-        double _rho{0};
+        Box bounds_;
+        double level_{0};
     };
 
+    // double-exponential disk with optional inner cavity and truncations (ExpDiskGeometry.cpp:13-90)
     class ExpDiskGeometry : public Geometry
     {
     public:
-        ExpDiskGeometry(double hR, double hz, double Rmin, double Rmax, double zmax);
+        ExpDiskGeometry(double radialScale, double verticalScale, double innerRadius, double outerRadius, double maxHeight);
         std::string type() const override { return "ExpDiskGeometry"; }
         double density(Vec3 r) const override;
-        double SigmaX() const override { return 2.0 * SigmaR(); }
-        double SigmaY() const override { return 2.0 * SigmaR(); }
-        double SigmaZ() const override;
-        double SigmaR() const;
-        Vec3 generatePosition(Random& random) const override;  // SepAxGeometry.cpp:11-19, ExpDiskGeometry.cpp:46-68
-        void parameters(double v[5]) const { v[0] = _hR, v[1] = _hz, v[2] = _Rmin, v[3] = _Rmax, v[4] = _zmax; }
+        double columnX() const override { return 2.0 * radialColumn(); }
+        double columnY() const override { return 2.0 * radialColumn(); }
+        double columnZ() const override;
+        double radialColumn() const;
+        Vec3 samplePosition(Random& random) const override;  // SepAxGeometry.cpp:11-19, ExpDiskGeometry.cpp:46-68
+        void parameters(double v[5]) const { v[0] = scaleR_, v[1] = scaleZ_, v[2] = innerR_, v[3] = outerR_, v[4] = maxZ_; }
 
     private:
-        double _hR, _hz, _Rmin, _Rmax, _zmax, _rho0;
+        double scaleR_, scaleZ_, innerR_, outerR_, maxZ_, central_;
     };
 
     class SersicGeometry : public Geometry
     {
     public:
-        SersicGeometry(double reff, double n);
+        SersicGeometry(double effectiveRadius, double index);
         std::string type() const override { return "SersicGeometry"; }
         double density(Vec3 r) const override;
-        double SigmaX() const override { return 2.0 * Sigmar(); }
-        double SigmaY() const override { return 2.0 * Sigmar(); }
-        double SigmaZ() const override { return 2.0 * Sigmar(); }
-        double Sigmar() const;
-        Vec3 generatePosition(Random& random) const override;  // SpheGeometry.cpp:25-32, SersicGeometry.cpp:41-45
-        double reff() const { return _reff; }
-        const SersicFunction& function() const { return *_function; }
+        double columnX() const override { return 2.0 * radialColumn(); }
+        double columnY() const override { return 2.0 * radialColumn(); }
+        double columnZ() const override { return 2.0 * radialColumn(); }
+        double radialColumn() const;
+        Vec3 samplePosition(Random& random) const override;  // SpheGeometry.cpp:25-32, SersicGeometry.cpp:41-45
+        double effectiveRadius() const { return reff_; }
+        const SersicProfile& profile() const { return *profile_; }
 
     private:
-        double _reff, _n, _rho0, _b;
-        std::unique_ptr<SersicFunction> _function;
+        double reff_, index_, central_, b_;
+        std::unique_ptr<SersicProfile> profile_;
     };
 
     class PlummerGeometry : public Geometry
     {
     public:
-        explicit PlummerGeometry(double c);
+        explicit PlummerGeometry(double scale);
         std::string type() const override { return "PlummerGeometry"; }
         double density(Vec3 r) const override;
-        double SigmaX() const override { return 2.0 * Sigmar(); }
-        double SigmaY() const override { return 2.0 * Sigmar(); }
-        double SigmaZ() const override { return 2.0 * Sigmar(); }
-        double Sigmar() const;
-        Vec3 generatePosition(Random& random) const override;  // SpheGeometry.cpp:25-32, PlummerGeometry.cpp:29-33
-        double scaleLength() const { return _c; }
+        double columnX() const override { return 2.0 * radialColumn(); }
+        double columnY() const override { return 2.0 * radialColumn(); }
+        double columnZ() const override { return 2.0 * radialColumn(); }
+        double radialColumn() const;
+        Vec3 samplePosition(Random& random) const override;  // SpheGeometry.cpp:25-32, PlummerGeometry.cpp:29-33
+        double scaleLength() const { return scale_; }
 
     private:
-        double _c, _rho0;
+        double scale_, central_;
     };
 
-    // SpheroidalGeometryDecorator (SpheroidalGeometryDecorator.cpp:11-43): a spherical geometry flattened along z by q
+    // SpheroidalGeometryDecorator (SpheroidalGeometryDecorator.cpp:11-43): a spherical geometry flattened along z
     class SpheroidalGeometry : public Geometry
     {
     public:
-        SpheroidalGeometry(std::unique_ptr<Geometry> spherical, double q) : _inner(std::move(spherical)), _q(q) {}
+        SpheroidalGeometry(std::unique_ptr<Geometry> spherical, double flattening) : sphere_(std::move(spherical)), flat_(flattening) {}
         std::string type() const override { return "SpheroidalGeometryDecorator"; }
         double density(Vec3 r) const override;
-        double SigmaX() const override { return 2.0 * SigmaR(); }
-        double SigmaY() const override { return 2.0 * SigmaR(); }
-        double SigmaZ() const override { return 2.0 * (_inner->SigmaX() / 2.0); }
-        double SigmaR() const { return 1.0 / _q * (_inner->SigmaX() / 2.0); }
-        Vec3 generatePosition(Random& random) const override;
-        const Geometry* inner() const { return _inner.get(); }
-        double flattening() const { return _q; }
+        double columnX() const override { return 2.0 * radialColumn(); }
+        double columnY() const override { return 2.0 * radialColumn(); }
+        double columnZ() const override { return 2.0 * (sphere_->columnX() / 2.0); }
+        double radialColumn() const { return 1.0 / flat_ * (sphere_->columnX() / 2.0); }
+        Vec3 samplePosition(Random& random) const override;
+        const Geometry* inner() const { return sphere_.get(); }
+        double flattening() const { return flat_; }
 
     private:
-        std::unique_ptr<Geometry> _inner;
-        double _q;
+        std::unique_ptr<Geometry> sphere_;
+        double flat_;
     };
 
     // OffsetGeometryDecorator (OffsetGeometryDecorator.cpp:18-52): any geometry shifted by a fixed vector
     class OffsetGeometry : public Geometry
     {
     public:
-        OffsetGeometry(std::unique_ptr<Geometry> geometry, Vec3 offset) : _inner(std::move(geometry)), _offset(offset) {}
+        OffsetGeometry(std::unique_ptr<Geometry> geometry, Vec3 shift) : base_(std::move(geometry)), shift_(shift) {}
         std::string type() const override { return "OffsetGeometryDecorator"; }
-        double density(Vec3 r) const override { return _inner->density(Vec3{r.x - _offset.x, r.y - _offset.y, r.z - _offset.z}); }
-        double SigmaX() const override { return _inner->SigmaX(); }
-        double SigmaY() const override { return _inner->SigmaY(); }
-        double SigmaZ() const override { return _inner->SigmaZ(); }
-        Vec3 generatePosition(Random& random) const override
+        double density(Vec3 r) const override { return base_->density(Vec3{r.x - shift_.x, r.y - shift_.y, r.z - shift_.z}); }
+        double columnX() const override { return base_->columnX(); }
+        double columnY() const override { return base_->columnY(); }
+        double columnZ() const override { return base_->columnZ(); }
+        Vec3 samplePosition(Random& random) const override
         {
-            Vec3 r = _inner->generatePosition(random);
-            return Vec3{r.x + _offset.x, r.y + _offset.y, r.z + _offset.z};
+            const Vec3 p = base_->samplePosition(random);
+            return Vec3{p.x + shift_.x, p.y + shift_.y, p.z + shift_.z};
         }
-        const Geometry* inner() const { return _inner.get(); }
-        Vec3 offset() const { return _offset; }
+        const Geometry* inner() const { return base_.get(); }
+        Vec3 offset() const { return shift_; }
 
     private:
-        std::unique_ptr<Geometry> _inner;
-        Vec3 _offset;
+        std::unique_ptr<Geometry> base_;
+        Vec3 shift_;
+    };
+
+    // radial power law A r^-p between two radii: normalisation and radius sampling shared by the shell and the torus
+    // (ShellGeometry.cpp:12-51, TorusGeometry.cpp:12-35,75-85)
+    struct PowerLawRadius
+    {
+        double inner{0}, outer{0}, exponent{0};
+        double logInner{0}, logSpan{0}, powInner{0}, powOuter{0};
+        void prepare(double rmin, double rmax, double p);
+        double sample(double X) const;
+        double column(double amplitude) const;  // A * integral of r^-p over the radial range
     };
 
     // ShellGeometry (ShellGeometry.cpp:12-58): power-law shell A r^-p between two radii
@@ -189,51 +206,52 @@ namespace skh
         ShellGeometry(double rmin, double rmax, double p);
         std::string type() const override { return "ShellGeometry"; }
         double density(Vec3 r) const override;
-        double SigmaX() const override { return 2.0 * Sigmar(); }
-        double SigmaY() const override { return 2.0 * Sigmar(); }
-        double SigmaZ() const override { return 2.0 * Sigmar(); }
-        double Sigmar() const;
-        Vec3 generatePosition(Random& random) const override;  // SpheGeometry.cpp:25-32, ShellGeometry.cpp:38-51
+        double columnX() const override { return 2.0 * radialColumn(); }
+        double columnY() const override { return 2.0 * radialColumn(); }
+        double columnZ() const override { return 2.0 * radialColumn(); }
+        double radialColumn() const { return radial_.column(amplitude_); }
+        Vec3 samplePosition(Random& random) const override;  // SpheGeometry.cpp:25-32, ShellGeometry.cpp:38-51
 
     private:
-        double _rmin, _rmax, _p, _smin, _sdiff, _tmin, _tmax, _A;
+        PowerLawRadius radial_;
+        double amplitude_;
     };
 
     // TorusGeometry (TorusGeometry.cpp:12-108): A r^-p exp(-q |cos theta|) within the opening angle
     class TorusGeometry : public Geometry
     {
     public:
-        TorusGeometry(double p, double q, double Delta, double rmin, double rmax, bool rani, double rcut);
+        TorusGeometry(double p, double q, double halfOpening, double rmin, double rmax, bool anisotropicInner, double cutoffRadius);
         std::string type() const override { return "TorusGeometry"; }
         double density(Vec3 r) const override;
-        double SigmaX() const override { return 2.0 * SigmaR(); }
-        double SigmaY() const override { return 2.0 * SigmaR(); }
-        double SigmaZ() const override { return 0.0; }
-        double SigmaR() const;
-        Vec3 generatePosition(Random& random) const override;
+        double columnX() const override { return 2.0 * radialColumn(); }
+        double columnY() const override { return 2.0 * radialColumn(); }
+        double columnZ() const override { return 0.0; }
+        double radialColumn() const { return radial_.column(amplitude_); }
+        Vec3 samplePosition(Random& random) const override;
 
     private:
-        double _p, _q, _Delta, _rmin, _rmax;
-        bool _rani;
-        double _rcut, _sinDelta, _smin, _sdiff, _tmin, _tmax, _A;
+        PowerLawRadius radial_;
+        double polar_, sinOpening_, cutoff_, amplitude_;
+        bool anisotropic_;
     };
 
     // RingGeometry (RingGeometry.cpp:13-77): Gaussian ring with an exponential vertical profile
     class RingGeometry : public Geometry
     {
     public:
-        RingGeometry(double R0, double w, double hz);
+        RingGeometry(double ringRadius, double width, double verticalScale);
         std::string type() const override { return "RingGeometry"; }
         double density(Vec3 r) const override;
-        double SigmaX() const override { return 2.0 * SigmaR(); }
-        double SigmaY() const override { return 2.0 * SigmaR(); }
-        double SigmaZ() const override;
-        double SigmaR() const;
-        Vec3 generatePosition(Random& random) const override;  // SepAxGeometry.cpp:11-19, RingGeometry.cpp:50-61
+        double columnX() const override { return 2.0 * radialColumn(); }
+        double columnY() const override { return 2.0 * radialColumn(); }
+        double columnZ() const override;
+        double radialColumn() const;
+        Vec3 samplePosition(Random& random) const override;  // SepAxGeometry.cpp:11-19, RingGeometry.cpp:50-61
 
     private:
-        double _R0, _w, _hz, _A;
-        Array _Rv, _Xv;
+        double centre_, width_, scaleZ_, amplitude_;
+        Array tableR_, tableCdf_;
     };
 
     // ---------------------------------------------------------------- dust mix (tabulated mean properties)
@@ -252,7 +270,7 @@ namespace skh
         Array sigmaAbs, sigmaSca, sigmaExt, asymmpar;
 
         void setup(double rangeMin, double rangeMax, const std::vector<double>& simulationWavelengths);
-        int indexForLambda(double lambda) const { return nr::locateClip(lambdaBorder, lambda); }
+        int indexForLambda(double lambda) const { return tab::bracketClipped(lambdaBorder, lambda); }
         double sectionExt(double lambda) const { return sigmaExt[indexForLambda(lambda)]; }
         double sectionSca(double lambda) const { return sigmaSca[indexForLambda(lambda)]; }
         double mass() const { return mu; }
@@ -314,7 +332,7 @@ namespace skh
         double massDensity(Vec3 r) const override { return mass * geometry->density(r); }
         double totalMass() const override { return mass; }
         double totalNumber() const override { return number; }
-        Vec3 generatePosition(Random& random) const override { return geometry->generatePosition(random); }
+        Vec3 generatePosition(Random& random) const override { return geometry->samplePosition(random); }
         double normalizationWavelength() const override
         {
             return normType == "OpticalDepthMaterialNormalization" ? normWavelength : 0.;

@@ -63,113 +63,103 @@ namespace skh
         throw std::runtime_error("smoothing kernel " + type + " is not supported on the MI355X path");
     }
 
-    // ================================================================ BoxSearch
+    // ================================================================ block search grid (BoxSearch.cpp:14-127)
 
     namespace
     {
-        // BoxSearch.cpp:14-52
-        void makegrid(Array& grid, const std::vector<Box>& boxv, int axis, int gridsize, double cmin, double cmax)
+        // Separators of one axis that put about the same number of entity centres into every slab: a histogram of the
+        // centres with 100 bins per slab, then a separator at the upper edge of the bin in which the running count passes
+        // the next multiple of (entities / slabs) -- at most one separator per bin; separators that are never reached stay
+        // zero, the outermost ones are infinite.
+        Array balancedSeparators(const Array& centres, int slabs, double lower, double upper)
         {
-            if (cmin == cmax)
+            if (lower == upper)
             {
-                double eps = 1e-12 * (cmin ? std::abs(cmin) : 1.);
-                cmin -= eps;
-                cmax += eps;
+                // a degenerate extent is widened by a relative 1e-12
+                const double margin = 1e-12 * (lower ? std::abs(lower) : 1.);
+                lower -= margin;
+                upper += margin;
             }
-            int nbins = gridsize * 100;
-            double binwidth = (cmax - cmin) / nbins;
-            std::vector<int> bins(nbins);
-            for (const auto& box : boxv)
+            const int bins = slabs * 100;
+            const double width = (upper - lower) / bins;
+            std::vector<int> histogram(bins);
+            for (double centre : centres) histogram[static_cast<int>((centre - lower) / width)] += 1;
+
+            const double quota = static_cast<double>(centres.size()) / slabs;
+            const double infinite = std::numeric_limits<double>::infinity();
+            Array separators(slabs + 1, 0.);
+            separators.front() = -infinite;
+            separators.back() = infinite;
+            int running = 0, next = 1;
+            for (int bin = 0; bin < bins && next < slabs; ++bin)
             {
-                double center = 0.;
-                switch (axis)
-                {
-                    case 1: center = 0.5 * (box.xmin + box.xmax); break;
-                    case 2: center = 0.5 * (box.ymin + box.ymax); break;
-                    case 3: center = 0.5 * (box.zmin + box.zmax); break;
-                }
-                bins[static_cast<int>((center - cmin) / binwidth)] += 1;
+                running += histogram[bin];
+                if (running > quota * next) separators[next++] = lower + (bin + 1) * width;
             }
-            double perblock = static_cast<double>(boxv.size()) / gridsize;
-            grid.assign(gridsize + 1, 0.);
-            grid[0] = -std::numeric_limits<double>::infinity();
-            int cumul = 0;
-            int gridindex = 1;
-            for (int binindex = 0; binindex < nbins; binindex++)
-            {
-                cumul += bins[binindex];
-                if (cumul > perblock * gridindex)
-                {
-                    grid[gridindex] = cmin + (binindex + 1) * binwidth;
-                    gridindex += 1;
-                    if (gridindex >= gridsize) break;
-                }
-            }
-            grid[gridsize] = std::numeric_limits<double>::infinity();
+            return separators;
         }
 
-        inline double square(double x) { return x * x; }
-        // Box::intersects(Vec rc, double r) (SKIRT/utils/Box.cpp:91-109)
-        bool boxIntersectsSphere(const Box& b, double cx, double cy, double cz, double r)
+        // does the sphere (centre c, radius r) reach into the box?  The squared radius minus the squared distance from
+        // the centre to the box, accumulated axis by axis (Box.cpp:91-109)
+        bool sphereReachesBox(const Box& box, double cx, double cy, double cz, double r)
         {
-            double squaredist = square(r);
-            if (cx < b.xmin)
-                squaredist -= square(cx - b.xmin);
-            else if (cx > b.xmax)
-                squaredist -= square(cx - b.xmax);
-            if (cy < b.ymin)
-                squaredist -= square(cy - b.ymin);
-            else if (cy > b.ymax)
-                squaredist -= square(cy - b.ymax);
-            if (cz < b.zmin)
-                squaredist -= square(cz - b.zmin);
-            else if (cz > b.zmax)
-                squaredist -= square(cz - b.zmax);
-            return squaredist >= 0.;
+            auto outside = [](double c, double low, double high) { return c < low ? c - low : c > high ? c - high : 0.; };
+            const double ex = outside(cx, box.xmin, box.xmax);
+            const double ey = outside(cy, box.ymin, box.ymax);
+            const double ez = outside(cz, box.zmin, box.zmax);
+            double remaining = r * r;
+            remaining -= ex * ex;
+            remaining -= ey * ey;
+            remaining -= ez * ez;
+            return remaining >= 0.;
         }
     }
 
     template<class Bounds, class Intersects> void BoxSearch::loadEntities(int numEntities, Bounds bounds, Intersects intersects)
     {
         _listv.clear();
-        if (numEntities <= 0)
-        {
-            _extent = Box();
-            _numBlocks = 0;
-            return;
-        }
-        std::vector<Box> boxv;
-        boxv.reserve(numEntities);
-        for (int m = 0; m != numEntities; ++m) boxv.emplace_back(bounds(m));
-        _extent = boxv[0];
-        for (const auto& box : boxv)
-        {
-            _extent.xmin = std::min(_extent.xmin, box.xmin);
-            _extent.ymin = std::min(_extent.ymin, box.ymin);
-            _extent.zmin = std::min(_extent.zmin, box.zmin);
-            _extent.xmax = std::max(_extent.xmax, box.xmax);
-            _extent.ymax = std::max(_extent.ymax, box.ymax);
-            _extent.zmax = std::max(_extent.zmax, box.zmax);
-        }
-        _numBlocks = std::max(10, static_cast<int>(std::cbrt(numEntities)));
-        makegrid(_xgrid, boxv, 1, _numBlocks, _extent.xmin, _extent.xmax);
-        makegrid(_ygrid, boxv, 2, _numBlocks, _extent.ymin, _extent.ymax);
-        makegrid(_zgrid, boxv, 3, _numBlocks, _extent.zmin, _extent.zmax);
-        _listv.resize(static_cast<size_t>(_numBlocks) * _numBlocks * _numBlocks);
+        _extent = Box();
+        _numBlocks = 0;
+        if (numEntities <= 0) return;
+
+        // bounding boxes, their union, and their centres per axis
+        std::vector<Box> boxes(numEntities);
+        Array midX(numEntities), midY(numEntities), midZ(numEntities);
         for (int m = 0; m != numEntities; ++m)
         {
-            const auto& box = boxv[m];
-            int i1 = nr::locateClip(_xgrid, box.xmin);
-            int i2 = nr::locateClip(_xgrid, box.xmax);
-            int j1 = nr::locateClip(_ygrid, box.ymin);
-            int j2 = nr::locateClip(_ygrid, box.ymax);
-            int k1 = nr::locateClip(_zgrid, box.zmin);
-            int k2 = nr::locateClip(_zgrid, box.zmax);
-            for (int i = i1; i <= i2; i++)
-                for (int j = j1; j <= j2; j++)
-                    for (int k = k1; k <= k2; k++)
+            const Box box = bounds(m);
+            boxes[m] = box;
+            midX[m] = 0.5 * (box.xmin + box.xmax);
+            midY[m] = 0.5 * (box.ymin + box.ymax);
+            midZ[m] = 0.5 * (box.zmin + box.zmax);
+            if (m == 0) _extent = box;
+            _extent = Box(std::min(_extent.xmin, box.xmin), std::min(_extent.ymin, box.ymin), std::min(_extent.zmin, box.zmin),
+                          std::max(_extent.xmax, box.xmax), std::max(_extent.ymax, box.ymax), std::max(_extent.zmax, box.zmax));
+        }
+        _numBlocks = std::max(10, static_cast<int>(std::cbrt(numEntities)));
+        _xgrid = balancedSeparators(midX, _numBlocks, _extent.xmin, _extent.xmax);
+        _ygrid = balancedSeparators(midY, _numBlocks, _extent.ymin, _extent.ymax);
+        _zgrid = balancedSeparators(midZ, _numBlocks, _extent.zmin, _extent.zmax);
+
+        // every entity is listed in the blocks its bounding box overlaps and it actually intersects; entities are visited in
+        // index order, so every list is ascending
+        _listv.resize(static_cast<size_t>(_numBlocks) * _numBlocks * _numBlocks);
+        struct Span
+        {
+            int first, last;
+        };
+        auto span = [](const Array& separators, double low, double high) {
+            return Span{tab::bracketClipped(separators, low), tab::bracketClipped(separators, high)};
+        };
+        for (int m = 0; m != numEntities; ++m)
+        {
+            const Box& box = boxes[m];
+            const Span sx = span(_xgrid, box.xmin, box.xmax), sy = span(_ygrid, box.ymin, box.ymax), sz = span(_zgrid, box.zmin, box.zmax);
+            for (int i = sx.first; i <= sx.last; ++i)
+                for (int j = sy.first; j <= sy.last; ++j)
+                    for (int k = sz.first; k <= sz.last; ++k)
                     {
-                        Box block(_xgrid[i], _ygrid[j], _zgrid[k], _xgrid[i + 1], _ygrid[j + 1], _zgrid[k + 1]);
+                        const Box block(_xgrid[i], _ygrid[j], _zgrid[k], _xgrid[i + 1], _ygrid[j + 1], _zgrid[k + 1]);
                         if (intersects(m, block)) _listv[blockIndex(i, j, k)].push_back(m);
                     }
         }
@@ -178,9 +168,9 @@ namespace skh
     const std::vector<int>& BoxSearch::entitiesFor(Vec3 r) const
     {
         if (!_numBlocks) return _empty;
-        int i = nr::locateClip(_xgrid, r.x);
-        int j = nr::locateClip(_ygrid, r.y);
-        int k = nr::locateClip(_zgrid, r.z);
+        int i = tab::bracketClipped(_xgrid, r.x);
+        int j = tab::bracketClipped(_ygrid, r.y);
+        int k = tab::bracketClipped(_zgrid, r.z);
         return _listv[blockIndex(i, j, k)];
     }
 
@@ -389,7 +379,7 @@ namespace skh
                 const Particle& p = _pv[m];
                 return Box(p.x - p.h, p.y - p.h, p.z - p.h, p.x + p.h, p.y + p.h, p.z + p.h);
             },
-            [this](int m, const Box& box) { return boxIntersectsSphere(box, _pv[m].x, _pv[m].y, _pv[m].z, _pv[m].h); });
+            [this](int m, const Box& box) { return sphereReachesBox(box, _pv[m].x, _pv[m].y, _pv[m].z, _pv[m].h); });
 
         // ---- optional: the same evaluation on the MI355X (include/pmc.h pmc_sampler_*)
         if (_api.create && !_pv.empty())

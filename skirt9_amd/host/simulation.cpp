@@ -107,7 +107,7 @@ namespace skh
                 int n = rd.integer(e, "numWavelengths", 25);
                 if (hi <= lo) throw std::runtime_error("the longest wavelength should be larger than the shortest");
                 Array lambdav;
-                nr::logGrid(lambdav, lo, hi, n - 1);
+                tab::logGrid(lambdav, lo, hi, n - 1);
                 grid->setWavelengthRange(lambdav, true);
             }
             else if (e.name == "LinWavelengthGrid")
@@ -117,7 +117,7 @@ namespace skh
                 int n = rd.integer(e, "numWavelengths", 25);
                 if (hi <= lo) throw std::runtime_error("the longest wavelength should be larger than the shortest");
                 Array lambdav;
-                nr::linearGrid(lambdav, lo, hi, n - 1);
+                tab::linearGrid(lambdav, lo, hi, n - 1);
                 grid->setWavelengthRange(lambdav, false);
             }
             else if (e.name == "ListWavelengthGrid")
@@ -744,20 +744,20 @@ namespace skh
             for (size_t j = minRight; j < maxRight;) xv[i++] = inxv[j++];
             xv[i++] = hi;
             pv.assign(n + 1, 0.);
-            pv[0] = minRight == 0 ? 0. : nr::interpolateLogLog(xv[0], inxv[minRight - 1], inxv[minRight], inpv[minRight - 1], inpv[minRight]);
+            pv[0] = minRight == 0 ? 0. : tab::logLog(xv[0], inxv[minRight - 1], inxv[minRight], inpv[minRight - 1], inpv[minRight]);
             for (size_t q = 1; q < n; ++q) pv[q] = inpv[minRight + q - 1];
             pv[n] = maxRight == inxv.size()
                         ? 0.
-                        : nr::interpolateLogLog(xv[n], inxv[maxRight - 1], inxv[maxRight], inpv[maxRight - 1], inpv[maxRight]);
-            return nr::cdf2(true, xv, pv, Pv);
+                        : tab::logLog(xv[n], inxv[maxRight - 1], inxv[maxRight], inpv[maxRight - 1], inpv[maxRight]);
+            return tab::cumulative(true, xv, pv, Pv);
         };
         auto planckCdf = [&](Array& lambdav, Array& pv, Array& Pv, double lo, double hi) {
             if (tabulated) return tableCdf(lambdav, pv, Pv, _source.sedInLambda, _source.sedInP, lo, hi);
             size_t n = std::max(static_cast<size_t>(100), static_cast<size_t>(1000. * log10(hi / lo)));
-            nr::logGrid(lambdav, lo, hi, static_cast<int>(n));
+            tab::logGrid(lambdav, lo, hi, static_cast<int>(n));
             pv.resize(n + 1);
             for (size_t i = 0; i <= n; ++i) pv[i] = planck(lambdav[i]);
-            return nr::cdf2(true, lambdav, pv, Pv);
+            return tab::cumulative(true, lambdav, pv, Pv);
         };
         double Ltot = planckCdf(_sedLambda, _sedp, _sedP, sourceMin, sourceMax);
         if (tabulated)
@@ -765,9 +765,9 @@ namespace skh
         auto specificLuminosity = [&](double lambda) {
             if (!tabulated) return planck(lambda) / Ltot;
             // NR::value<NR::interpolateLogLog> (NR.hpp:372-378)
-            int i = nr::locateFail(_source.sedInLambda, lambda);
+            int i = tab::bracketOrMiss(_source.sedInLambda, lambda);
             if (i < 0 || lambda < _source.sedInLambda.front()) return 0.;
-            return nr::interpolateLogLog(lambda, _source.sedInLambda[i], _source.sedInLambda[i + 1], _source.sedInP[i], _source.sedInP[i + 1]);
+            return tab::logLog(lambda, _source.sedInLambda[i], _source.sedInLambda[i + 1], _source.sedInP[i], _source.sedInP[i + 1]);
         };
 
         // IntegratedLuminosityNormalization::luminosityForSED (IntegratedLuminosityNormalization.cpp:12-31)
@@ -909,10 +909,10 @@ namespace skh
         else if (auto sersic = dynamic_cast<const SersicGeometry*>(shape))
         {
             s.kind = PMC_SOURCE_SERSIC;
-            s.reff = sersic->reff();
-            s.sersic_n = static_cast<int32_t>(sersic->function().sv().size());
-            s.sersic_s = sersic->function().sv().data();
-            s.sersic_M = sersic->function().Mv().data();
+            s.reff = sersic->effectiveRadius();
+            s.sersic_n = static_cast<int32_t>(sersic->profile().radii().size());
+            s.sersic_s = sersic->profile().radii().data();
+            s.sersic_M = sersic->profile().masses().data();
         }
         else if (auto ubox = dynamic_cast<const UniformBoxGeometry*>(shape))
         {
