@@ -66,10 +66,11 @@
     #define PMC_PEEL_BLOCK 512  // lanes per workgroup of the peel-off kernel (one coordinate table in LDS per workgroup)
 #endif
 #ifndef PMC_PEEL_MIN_WAVES
-    #define PMC_PEEL_MIN_WAVES 8  // waves per SIMD the peel-off kernel's register budget must allow (<= 64 VGPRs)
+    #define PMC_PEEL_MIN_WAVES 6  // waves per SIMD the peel-off kernel's register budget must allow (<= 80 VGPRs; it uses 65,
+                                  // and must not spill: see treeSlowStep)
 #endif
 #ifndef PMC_PROP_MIN_WAVES
-    #define PMC_PROP_MIN_WAVES 4  // likewise for the propagation kernel (<= 128 VGPRs)
+    #define PMC_PROP_MIN_WAVES 3  // likewise for the propagation kernel (<= 168 VGPRs; it uses 135-143)
 #endif
 #ifndef PMC_WALK_MIN_WAVES
     #define PMC_WALK_MIN_WAVES 1  // waves per SIMD the walk kernel's register budget must allow

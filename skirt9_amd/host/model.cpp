@@ -469,27 +469,29 @@ namespace skh
             throw std::runtime_error("Number of listed properties does not match number of listed wavelengths");
         if (inLambda.empty()) throw std::runtime_error("Dust properties must be tabulated for at least one wavelength");
 
-        // fine grid at integer multiples of 1/1000 dex + all configured wavelengths (DustMix.cpp:57-72)
-        std::vector<double> wavelengths;
-        const double numWavelengthsPerDex = 1000;
-        int minLambdaSerial = std::floor(numWavelengthsPerDex * log10(rangeMin));
-        int maxLambdaSerial = std::ceil(numWavelengthsPerDex * log10(rangeMax));
-        for (int k = minLambdaSerial; k <= maxLambdaSerial; ++k) wavelengths.push_back(pow(10., k / numWavelengthsPerDex));
-        for (double lambda : simulationWavelengths) wavelengths.push_back(lambda);
-        std::sort(wavelengths.begin(), wavelengths.end());
-        wavelengths.erase(std::unique(wavelengths.begin(), wavelengths.end()), wavelengths.end());
+        // sample wavelengths: every integer multiple of 1/1000 dex inside the range, plus all configured wavelengths
+        // (DustMix.cpp:57-72)
+        const double perDecade = 1000;
+        const int firstTick = std::floor(perDecade * log10(rangeMin));
+        const int lastTick = std::ceil(perDecade * log10(rangeMax));
+        std::vector<double> samples;
+        samples.reserve(lastTick - firstTick + 1 + simulationWavelengths.size());
+        for (int tick = firstTick; tick <= lastTick; ++tick) samples.push_back(pow(10., tick / perDecade));
+        samples.insert(samples.end(), simulationWavelengths.begin(), simulationWavelengths.end());
+        std::sort(samples.begin(), samples.end());
+        samples.erase(std::unique(samples.begin(), samples.end()), samples.end());
 
-        // radio cutoff beyond 10 cm (DustMix.cpp:74-82)
-        const double dm = 0.1;
-        bool radioCutoff = wavelengths.back() > dm;
-        if (radioCutoff)
+        // beyond 10 cm the dust is transparent: the table ends with 10 cm and one point just above it (DustMix.cpp:74-82)
+        const double tenCm = 0.1;
+        const bool beyondRadio = samples.back() > tenCm;
+        if (beyondRadio)
         {
-            wavelengths.resize(tab::bracket(wavelengths, dm) + 1);
-            if (wavelengths.empty() || wavelengths.back() != dm) wavelengths.push_back(dm);
-            wavelengths.push_back(dm * 1.001);
+            samples.resize(tab::bracket(samples, tenCm) + 1);
+            if (samples.empty() || samples.back() != tenCm) samples.push_back(tenCm);
+            samples.push_back(tenCm * 1.001);
         }
-        lambdaSample = wavelengths;
-        int numLambda = static_cast<int>(lambdaSample.size());
+        lambdaSample = samples;
+        const int numLambda = static_cast<int>(lambdaSample.size());
 
         // index grid shifted to the left of the sample points (DustMix.cpp:93-98)
         lambdaBorder.assign(numLambda, 0.);
@@ -517,11 +519,11 @@ namespace skh
 
         // clamp g (DustMix.cpp:139-146), derive extinction (:160-162)
         const double gmax = 0.999999;
-        for (int ell = 0; ell != numLambda; ++ell)
+        for (int ell = 0; ell < numLambda; ++ell)
             if (std::abs(asymmpar[ell]) > gmax) asymmpar[ell] = std::copysign(gmax, asymmpar[ell]);
         sigmaExt.assign(numLambda, 0.);
-        for (int ell = 0; ell != numLambda; ++ell) sigmaExt[ell] = sigmaAbs[ell] + sigmaSca[ell];
-        if (radioCutoff)
+        for (int ell = 0; ell < numLambda; ++ell) sigmaExt[ell] = sigmaAbs[ell] + sigmaSca[ell];
+        if (beyondRadio)
         {
             sigmaAbs[numLambda - 2] = sigmaAbs[numLambda - 1] = 0.;
             sigmaSca[numLambda - 2] = sigmaSca[numLambda - 1] = 0.;
@@ -541,10 +543,10 @@ namespace skh
                 throw std::runtime_error("Can't normalize material for geometry with zero column density along selected axis");
             double section = mix->sectionExt(normWavelength);
             if (section <= 0.) throw std::runtime_error("Can't normalize optical depth for material with zero extinction");
-            double reqNumberColumnDensity = normOpticalDepth / section;
-            double reqMassColumnDensity = reqNumberColumnDensity * mix->mass();
-            number = reqNumberColumnDensity / geomColumnDensity;
-            mass = reqMassColumnDensity / geomColumnDensity;
+            const double numberColumn = normOpticalDepth / section;
+            const double massColumn = numberColumn * mix->mass();
+            number = numberColumn / geomColumnDensity;
+            mass = massColumn / geomColumnDensity;
         }
         else if (normType == "MassMaterialNormalization")
         {
@@ -560,6 +562,80 @@ namespace skh
             throw std::runtime_error("ski: material normalization '" + normType + "' is not supported on the MI355X path");
     }
 
+    // ================================================================ meshes on the unit interval
+
+    // Border points of the reference's mesh classes (LinMesh.cpp:11-16, PowMesh.cpp:11-19, SymPowMesh.cpp:11-19,
+    // LogMesh.cpp:11-19, SymLogMesh.cpp:11-42 with the grid builders of NR.hpp:203-320), n bins on [0, 1]
+    namespace mesh
+    {
+        // bin widths in geometric progression: the last bin is `ratio` times the first
+        Array geometric(int n, double ratio)
+        {
+            Array points(n + 1);
+            const double first = 0.0, span = 1.0 - 0.0;
+            const double step = pow(ratio, 1. / (n - 1));
+            const double whole = pow(step, n);
+            for (int k = 0; k <= n; ++k) points[k] = first + (1. - pow(step, k)) / (1. - whole) * span;
+            return points;
+        }
+        // the same progression mirrored about the centre: outermost bins `ratio` times the innermost
+        Array symmetricGeometric(int n, double ratio)
+        {
+            Array points(n + 1);
+            const double centre = 0.5 * (0.0 + 1.0);
+            const double halfSpan = 0.5;
+            const int half = n % 2 == 0 ? n / 2 : (n + 1) / 2;
+            const double step = pow(ratio, 1.0 / (half - 1.0));
+            const double whole = pow(step, half);
+            if (n % 2 == 0)
+            {
+                points[half] = centre;
+                for (int k = 1; k <= half; ++k)
+                {
+                    const double offset = (1.0 - pow(step, k)) / (1.0 - whole) * halfSpan;
+                    points[half + k] = centre + offset;
+                    points[half - k] = centre - offset;
+                }
+            }
+            else
+            {
+                // the central bin straddles the centre
+                const double pivot = 0.5 + 0.5 * step;
+                for (int k = 1; k <= half; ++k)
+                {
+                    const double offset = (pivot - pow(step, k)) / (pivot - whole) * halfSpan;
+                    points[half - 1 + k] = centre + offset;
+                    points[half - k] = centre - offset;
+                }
+            }
+            return points;
+        }
+        // first bin [0, fraction], the others logarithmic up to one
+        Array logarithmicFromZero(int n, double fraction)
+        {
+            Array points(n + 1, 0.);
+            const double origin = log(fraction);
+            const double spacing = log(1.0 / fraction) / (n - 1);
+            for (int k = 0; k < n; ++k) points[k + 1] = exp(origin + k * spacing);
+            return points;
+        }
+        // logarithmic bins away from the centre on both sides; central bin(s) of width `fraction` of a half
+        Array symmetricLogarithmic(int n, double fraction)
+        {
+            const int perSide = (n - 1) / 2;
+            Array side;
+            tab::logGrid(side, fraction, 1., perSide);
+            Array points;
+            points.reserve(n + 1);
+            points.push_back(0.);
+            for (int k = perSide - 1; k >= 0; --k) points.push_back(0.5 - 0.5 * side[k]);
+            if (n % 2 == 0) points.push_back(0.5);
+            for (int k = 0; k < perSide; ++k) points.push_back(0.5 + 0.5 * side[k]);
+            points.push_back(1.);
+            return points;
+        }
+    }
+
     // ================================================================ CartesianSpatialGrid
 
     void CartesianSpatialGrid::setup()
@@ -568,91 +644,25 @@ namespace skh
         // LogMesh.cpp:11-19, SymLogMesh.cpp:11-42 with the grid builders of NR.hpp:203-320), scaled as
         // CartesianSpatialGrid.cpp:22-24
         auto meshOf = [](const MeshSpec& spec, int n) {
-            Array tv;
+            const bool uniformRatio = fabs(spec.ratio - 1.) < 1e-3;
+            Array points;
             if (spec.type == "ListMesh")
-            {
-                tv.resize(spec.points.size());
-                for (size_t i = 0; i < spec.points.size(); ++i) tv[i] = spec.points[i];
-                return tv;
-            }
-            if (spec.type == "PowMesh" && n > 1)
-            {
-                // NR::buildPowerLawGrid
-                if (fabs(spec.ratio - 1.) < 1e-3)
-                    tab::linearGrid(tv, 0.0, 1.0, n);
-                else
-                {
-                    tv.resize(n + 1);
-                    double range = 1.0 - 0.0;
-                    double q = pow(spec.ratio, 1. / (n - 1));
-                    double qn = pow(q, n);
-                    for (int i = 0; i <= n; ++i) tv[i] = 0.0 + (1. - pow(q, i)) / (1. - qn) * range;
-                }
-            }
-            else if (spec.type == "SymPowMesh" && n > 2)
-            {
-                // NR::buildSymmetricPowerLawGrid
-                if (fabs(spec.ratio - 1.) < 1e-3)
-                    tab::linearGrid(tv, 0.0, 1.0, n);
-                else
-                {
-                    tv.resize(n + 1);
-                    const double xmin = 0.0, xmax = 1.0;
-                    double xc = 0.5 * (xmin + xmax);
-                    if (n % 2 == 0)
-                    {
-                        int M = n / 2;
-                        double q = pow(spec.ratio, 1.0 / (M - 1.0));
-                        double qM = pow(q, M);
-                        tv[M] = xc;
-                        for (int i = 1; i <= M; ++i)
-                        {
-                            double dxi = (1.0 - pow(q, i)) / (1.0 - qM) * 0.5 * (xmax - xmin);
-                            tv[M + i] = xc + dxi;
-                            tv[M - i] = xc - dxi;
-                        }
-                    }
-                    else
-                    {
-                        int M = (n + 1) / 2;
-                        double q = pow(spec.ratio, 1.0 / (M - 1.0));
-                        double qM = pow(q, M);
-                        for (int i = 1; i <= M; ++i)
-                        {
-                            double dxi = (0.5 + 0.5 * q - pow(q, i)) / (0.5 + 0.5 * q - qM) * 0.5 * (xmax - xmin);
-                            tv[M - 1 + i] = xc + dxi;
-                            tv[M - i] = xc - dxi;
-                        }
-                    }
-                }
-            }
+                points.assign(spec.points.begin(), spec.points.end());
+            else if (spec.type == "PowMesh" && n > 1 && !uniformRatio)
+                points = mesh::geometric(n, spec.ratio);
+            else if (spec.type == "SymPowMesh" && n > 2 && !uniformRatio)
+                points = mesh::symmetricGeometric(n, spec.ratio);
             else if (spec.type == "LogMesh" && n > 1)
-            {
-                // NR::buildZeroLogGrid(tv, centralBinFraction, 1, n)
-                tv.assign(n + 1, 0.);
-                double logxmin = log(spec.centralBinFraction);
-                double dlogx = log(1.0 / spec.centralBinFraction) / (n - 1);
-                for (int i = 0; i < n; i++) tv[i + 1] = exp(logxmin + i * dlogx);
-            }
+                points = mesh::logarithmicFromZero(n, spec.centralBinFraction);
             else if (spec.type == "SymLogMesh" && n > 2)
-            {
-                // the rightmost half as NR::buildLogGrid(tmpv, centralBinFraction, 1, n2), mirrored
-                int n2 = (n - 1) / 2;
-                Array tmpv(n2 + 1);
-                double logxmin = log(spec.centralBinFraction);
-                double dlogx = log(1. / spec.centralBinFraction) / n2;
-                for (int i = 0; i <= n2; i++) tmpv[i] = exp(logxmin + i * dlogx);
-                tv.assign(n + 1, 0.);
-                int k = 0;
-                tv[k++] = 0.;
-                for (int i = n2 - 1; i >= 0; --i) tv[k++] = 0.5 - 0.5 * tmpv[i];
-                if (n % 2 == 0) tv[k++] = 0.5;
-                for (int i = 0; i <= n2 - 1; ++i) tv[k++] = 0.5 + 0.5 * tmpv[i];
-                tv[k++] = 1.;
-            }
+                points = mesh::symmetricLogarithmic(n, spec.centralBinFraction);
             else
-                tab::linearGrid(tv, 0.0, 1.0, (spec.type == "PowMesh" || spec.type == "LogMesh") ? 1 : n);
-            return tv;
+            {
+                // uniform bins; a one-bin power-law or logarithmic mesh is the unit interval
+                const bool single = (spec.type == "PowMesh" || spec.type == "LogMesh") && n <= 1;
+                tab::linearGrid(points, 0.0, 1.0, single ? 1 : n);
+            }
+            return points;
         };
         const MeshSpec* specs = meshSpec;
         int axis = 0;
@@ -781,27 +791,27 @@ namespace skh
         // node (the order in which one reference thread consumes it), the densities are evaluated on all host cores
         const size_t batchNodes = std::max<size_t>(1, (size_t(1) << 22) / std::max(1, numDensitySamples));
         std::vector<Vec3> pos;
-        std::vector<double> rhov;
-        size_t lbeg = 0, lend = 1;
-        while (lend != lbeg)
+        std::vector<double> sampleDensities;
+        size_t levelFirst = 0, levelEnd = 1;
+        while (levelEnd != levelFirst)
         {
-            size_t numEvalNodes = lend - lbeg;
-            std::vector<char> divide(numEvalNodes, 0);
-            for (size_t b0 = 0; b0 < numEvalNodes; b0 += batchNodes)
+            size_t levelCount = levelEnd - levelFirst;
+            std::vector<char> divide(levelCount, 0);
+            for (size_t b0 = 0; b0 < levelCount; b0 += batchNodes)
             {
-                const size_t b1 = std::min(numEvalNodes, b0 + batchNodes);
+                const size_t b1 = std::min(levelCount, b0 + batchNodes);
                 pos.clear();
                 for (size_t l = b0; l != b1; ++l)
                 {
-                    const Node& node = nodes[lbeg + l];
+                    const Node& node = nodes[levelFirst + l];
                     if (node.level >= minLevel && node.level < maxLevel)
                         for (int i = 0; i != numDensitySamples; ++i) pos.push_back(random.position(node.box));
                 }
-                medium.massDensities(pos, rhov);
+                medium.massDensities(pos, sampleDensities);
                 size_t at = 0;
                 for (size_t l = b0; l != b1; ++l)
                 {
-                    const Node& node = nodes[lbeg + l];
+                    const Node& node = nodes[levelFirst + l];
                     bool need = false;
                     if (node.level < minLevel)
                         need = true;
@@ -809,33 +819,33 @@ namespace skh
                         need = false;
                     else
                     {
-                        double rhomin = DBL_MAX, rhomax = 0., rhosum = 0;
+                        double lowest = DBL_MAX, highest = 0., sampleSum = 0;
                         for (int i = 0; i != numDensitySamples; ++i)
                         {
-                            double rhoi = 0.;
-                            rhoi += rhov[at++];
-                            rhosum += rhoi;
-                            if (rhoi < rhomin) rhomin = rhoi;
-                            if (rhoi > rhomax) rhomax = rhoi;
+                            double sampled = 0.;
+                            sampled += sampleDensities[at++];
+                            sampleSum += sampled;
+                            if (sampled < lowest) lowest = sampled;
+                            if (sampled > highest) highest = sampled;
                         }
-                        double rho = rhosum / numDensitySamples;
+                        double rho = sampleSum / numDensitySamples;
                         double V = node.box.volume();
                         double M = rho * V;
                         if (hasDustFraction && M / dustMass > maxDustFraction) need = true;
                         if (!need && hasDustOpticalDepth && dustKappa * rho * node.box.diagonal() > maxDustOpticalDepth) need = true;
                         if (!need && hasDustDensityDispersion)
                         {
-                            double q = rhomax > 0 ? (rhomax - rhomin) / rhomax : 0.;
-                            if (q > maxDustDensityDispersion) need = true;
+                            const double contrast = highest > 0 ? (highest - lowest) / highest : 0.;
+                            if (contrast > maxDustDensityDispersion) need = true;
                         }
                     }
                     divide[l] = need;
                 }
             }
-            for (size_t l = 0; l != numEvalNodes; ++l)
-                if (divide[l]) subdivide(static_cast<int>(lbeg + l));
-            lbeg = lend;
-            lend = nodes.size();
+            for (size_t l = 0; l < levelCount; ++l)
+                if (divide[l]) subdivide(static_cast<int>(levelFirst + l));
+            levelFirst = levelEnd;
+            levelEnd = nodes.size();
         }
         finish();
     }
@@ -850,7 +860,7 @@ namespace skh
             // VoronoiMeshSpatialGrid.cpp:22-40,73-85 (sampleMedia with ONE dust medium: the uniform deviate that selects
             // the medium is consumed all the same), positions outside the domain are discarded
             sites.resize(numSites);
-            for (int m = 0; m != numSites;)
+            for (int m = 0; m < numSites;)
             {
                 (void)random.uniform();  // NR::locateClip(Xv, uniform) with Xv = {0, 1}
                 Vec3 p = medium.generatePosition(random);
@@ -929,10 +939,10 @@ namespace skh
         root.box = extent;
         nodes.push_back(root);
         std::vector<int> tmpOf{0};  // temporary id of each node id
-        size_t lbeg = 0, lend = 1;
-        while (lend != lbeg)
+        size_t levelFirst = 0, levelEnd = 1;
+        while (levelEnd != levelFirst)
         {
-            for (size_t l = lbeg; l != lend; ++l)
+            for (size_t l = levelFirst; l < levelEnd; ++l)
             {
                 if (tmp[tmpOf[l]].divided)
                 {
@@ -940,8 +950,8 @@ namespace skh
                     for (int c = 0; c < 8; ++c) tmpOf.push_back(tmp[tmpOf[l]].child[c]);
                 }
             }
-            lbeg = lend;
-            lend = nodes.size();
+            levelFirst = levelEnd;
+            levelEnd = nodes.size();
         }
         finish();
     }
@@ -969,7 +979,7 @@ namespace skh
         int numNodes = static_cast<int>(nodes.size());
         cellIndexOfNode.assign(numNodes, -1);
         nodeOfCell.clear();
-        for (int l = 0; l != numNodes; ++l)
+        for (int l = 0; l < numNodes; ++l)
             if (nodes[l].firstChild < 0)
             {
                 cellIndexOfNode[l] = static_cast<int>(nodeOfCell.size());
@@ -982,7 +992,7 @@ namespace skh
         flatCell.resize(numNodes);
         flatNbrStart.assign(6 * size_t(numNodes) + 1, 0);
         flatNbrList.clear();
-        for (int l = 0; l != numNodes; ++l)
+        for (int l = 0; l < numNodes; ++l)
         {
             const Box& b = nodes[l].box;
             double v[6] = {b.xmin, b.ymin, b.zmin, b.xmax, b.ymax, b.zmax};
@@ -1033,22 +1043,22 @@ namespace skh
         else if (logScale)
         {
             lambdaleftv[0] = borderv[0] = sqrt(lambdav[0] * lambdav[0] * lambdav[0] / lambdav[1]);
-            for (size_t ell = 1; ell != n; ++ell)
+            for (size_t ell = 1; ell < n; ++ell)
                 lambdarightv[ell - 1] = lambdaleftv[ell] = borderv[ell] = sqrt(lambdav[ell - 1] * lambdav[ell]);
             lambdarightv[n - 1] = borderv[n] = sqrt(lambdav[n - 1] * lambdav[n - 1] * lambdav[n - 1] / lambdav[n - 2]);
         }
         else
         {
             lambdaleftv[0] = borderv[0] = (3. * lambdav[0] - lambdav[1]) / 2.;
-            for (size_t ell = 1; ell != n; ++ell)
+            for (size_t ell = 1; ell < n; ++ell)
                 lambdarightv[ell - 1] = lambdaleftv[ell] = borderv[ell] = (lambdav[ell - 1] + lambdav[ell]) / 2.;
             lambdarightv[n - 1] = borderv[n] = (3. * lambdav[n - 1] - lambdav[n - 2]) / 2.;
         }
         if (lambdaleftv[0] <= 0.0) throw std::runtime_error("All wavelength bin borders should be positive");
         dlambdav.resize(n);
-        for (size_t ell = 0; ell != n; ++ell) dlambdav[ell] = lambdarightv[ell] - lambdaleftv[ell];
+        for (size_t ell = 0; ell < n; ++ell) dlambdav[ell] = lambdarightv[ell] - lambdaleftv[ell];
         ellv.assign(n + 2, -1);
-        for (size_t ell = 0; ell != n; ++ell) ellv[ell + 1] = static_cast<int32_t>(ell);
+        for (size_t ell = 0; ell < n; ++ell) ellv[ell + 1] = static_cast<int32_t>(ell);
     }
 
     void WavelengthGrid::setWavelengthBins(Array lambda, double relativeHalfWidth, bool constantWidth)
@@ -1063,7 +1073,7 @@ namespace skh
         borderv.assign(2 * n, 0.);
         if (!constantWidth)
         {
-            for (size_t ell = 0; ell != n; ++ell)
+            for (size_t ell = 0; ell < n; ++ell)
             {
                 borderv[2 * ell] = lambdaleftv[ell] = lambdav[ell] * (1. - relativeHalfWidth);
                 borderv[2 * ell + 1] = lambdarightv[ell] = lambdav[ell] * (1. + relativeHalfWidth);
@@ -1072,7 +1082,7 @@ namespace skh
         else
         {
             double delta = lambdav[0] * relativeHalfWidth;
-            for (size_t ell = 0; ell != n; ++ell)
+            for (size_t ell = 0; ell < n; ++ell)
             {
                 borderv[2 * ell] = lambdaleftv[ell] = lambdav[ell] - delta;
                 borderv[2 * ell + 1] = lambdarightv[ell] = lambdav[ell] + delta;
@@ -1081,9 +1091,9 @@ namespace skh
         if (!std::is_sorted(borderv.begin(), borderv.end()))
             throw std::runtime_error("Non-adjacent wavelength bins should not overlap");
         dlambdav.resize(n);
-        for (size_t ell = 0; ell != n; ++ell) dlambdav[ell] = lambdarightv[ell] - lambdaleftv[ell];
+        for (size_t ell = 0; ell < n; ++ell) dlambdav[ell] = lambdarightv[ell] - lambdaleftv[ell];
         ellv.assign(2 * n + 1, -1);
-        for (size_t ell = 0; ell != n; ++ell) ellv[2 * ell + 1] = static_cast<int32_t>(ell);
+        for (size_t ell = 0; ell < n; ++ell) ellv[2 * ell + 1] = static_cast<int32_t>(ell);
     }
 
     int WavelengthGrid::bin(double lambda) const

@@ -21,12 +21,11 @@ namespace skh
             std::string type() const override { return "CubicSplineSmoothingKernel"; }
             double density(double u) const override
             {
-                if (u < 0.0 || u >= 1.0)
-                    return 0.0;
-                else if (u < 0.5)
-                    return 8.0 / M_PI * (1.0 - 6.0 * u * u * (1.0 - u));
-                else
-                    return 8.0 / M_PI * 2.0 * (1.0 - u) * (1.0 - u) * (1.0 - u);
+                if (!(u >= 0.0 && u < 1.0)) return 0.0;
+                const double norm = 8.0 / M_PI;
+                const double rest = 1.0 - u;
+                if (u < 0.5) return norm * (1.0 - 6.0 * u * u * rest);  // inner half: 1 - 6 u^2 (1 - u)
+                return norm * 2.0 * rest * rest * rest;                 // outer half: 2 (1 - u)^3
             }
         };
         // ScaledGaussianSmoothingKernel.cpp:16-47
@@ -36,10 +35,10 @@ namespace skh
             std::string type() const override { return "ScaledGaussianSmoothingKernel"; }
             double density(double u) const override
             {
-                constexpr double N = 2.56810060330949540082;
-                constexpr double A = -5.85836755024609305208;
-                if (u < 0. || u > 1.) return 0.;
-                return N * exp(A * u * u);
+                // front factor and exponent of the Gaussian truncated at the smoothing length
+                static const double front = 2.56810060330949540082, exponent = -5.85836755024609305208;
+                if (!(u >= 0. && u <= 1.)) return 0.;
+                return front * exp(exponent * u * u);
             }
         };
         // UniformSmoothingKernel.cpp:13-17
@@ -49,8 +48,7 @@ namespace skh
             std::string type() const override { return "UniformSmoothingKernel"; }
             double density(double u) const override
             {
-                if (u < 0.0 || u > 1.0) return 0.0;
-                return 0.75 / M_PI;
+                return (u >= 0.0 && u <= 1.0) ? 0.75 / M_PI : 0.0;
             }
         };
     }
@@ -354,25 +352,25 @@ namespace skh
         // ParticleSnapshot::readAndClose (ParticleSnapshot.cpp:79-151)
         _pv.clear();
         _pv.reserve(rows.size());
-        double totalOriginalMass = 0, totalMetallicMass = 0, totalEffectiveMass = 0;
+        double sumImported = 0, sumMetallic = 0, sumEffective = 0;
         for (const Array& prop : rows)
         {
             if (useTemperatureCutoff && prop[temperatureIndex] > maxTemperature) continue;
             if (prop[massIndex] == 0.) continue;
-            double originalMass = prop[massIndex];
-            double metallicMass = originalMass * (useMetallicity ? prop[metallicityIndex] : 1.);
-            double effectiveMass = metallicMass * o.massFraction;
-            _pv.push_back(Particle{prop[0], prop[1], prop[2], prop[3], effectiveMass});
-            totalOriginalMass += originalMass;
-            totalMetallicMass += metallicMass;
-            totalEffectiveMass += effectiveMass;
+            double imported = prop[massIndex];
+            double metallic = imported * (useMetallicity ? prop[metallicityIndex] : 1.);
+            double effective = metallic * o.massFraction;
+            _pv.push_back(Particle{prop[0], prop[1], prop[2], prop[3], effective});
+            sumImported += imported;
+            sumMetallic += metallic;
+            sumEffective += effective;
         }
-        if (totalOriginalMass < 0 || totalMetallicMass < 0 || totalEffectiveMass < 0)
+        if (sumImported < 0 || sumMetallic < 0 || sumEffective < 0)
         {
             _pv.clear();
-            totalEffectiveMass = 0;
+            sumEffective = 0;
         }
-        _mass = totalEffectiveMass;
+        _mass = sumEffective;
         _search.loadEntities(
             static_cast<int>(_pv.size()),
             [this](int m) {
