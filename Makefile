@@ -25,6 +25,12 @@ skirt9_amd/lib/libpmc.so: $(wildcard skirt9_amd/csrc/*.hip) $(wildcard skirt9_am
 profile-lib: skirt9_amd/lib/libpmc_prof.so
 skirt9_amd/lib/libpmc_prof.so: $(wildcard skirt9_amd/csrc/*.hip) $(wildcard skirt9_amd/csrc/*.h) $(wildcard skirt9_amd/csrc/*.inc) $(wildcard include/*.h)
 	@mkdir -p skirt9_amd/lib
+	$(HIPCC) $(HIPFLAGS) -DPMC_PROFILE -DPMC_PROFILE_STAMPS -shared $(wildcard skirt9_amd/csrc/*.hip) -o $@
+
+# event census of the walk kernels without the time stamps (PMC_LIBRARY=.../libpmc_census.so PMC_PROFILE_DUMP=1)
+census-lib: skirt9_amd/lib/libpmc_census.so
+skirt9_amd/lib/libpmc_census.so: $(wildcard skirt9_amd/csrc/*.hip) $(wildcard skirt9_amd/csrc/*.h) $(wildcard skirt9_amd/csrc/*.inc) $(wildcard include/*.h)
+	@mkdir -p skirt9_amd/lib
 	$(HIPCC) $(HIPFLAGS) -DPMC_PROFILE -shared $(wildcard skirt9_amd/csrc/*.hip) -o $@
 
 skirt9_amd/lib/skirt_mi355x: skirt9_amd/host/main.cpp skirt9_amd/lib/libskirthost.so skirt9_amd/lib/libpmc.so

@@ -145,15 +145,15 @@ namespace
         int tabn{0};
         std::vector<double> table;       // [3][tabn]
         std::vector<LeafRec> leaves;     // by cell index m
-        std::vector<AxisRec> axis;       // [3][numCells]
+        std::vector<CellRec> cells;      // by device cell index: the walk step's hot record
         std::vector<NodeRec> internals;  // by internal index
         std::vector<int32_t> nbrStart, nbrList;
         uint32_t rootLink{0};
         int coarseLevel{0};
         std::vector<uint32_t> coarse;    // [2^Lc]^3 (z, y, x): link of the covering node at level <= Lc
-        // device numbering of the cells: dev = perm[m]; groups of 2^g consecutive cells (siblings: one sector of the
-        // per-axis table) stay together, the groups are scattered over the table so that the cells of a hot region do
-        // not share L2 channels; cellExt[dev] = m (or -1 for padding); cellSlots = entries per device table
+        // device numbering of the cells: dev = perm[m], depth-first order of the tree (the eight leaves of a node whose
+        // children are all leaves are consecutive, in child order); cellExt[dev] = m (or -1 for padding); cellSlots =
+        // entries per device table
         std::vector<int32_t> perm, cellExt;
         int cellSlots{0};
     };
@@ -223,18 +223,16 @@ namespace
                     if (std::isnan(mid))
                         mid = (T.table[size_t(axis) * T.tabn + lo] + T.table[size_t(axis) * T.tabn + lo + size]) / 2.;
                 }
-        // device numbering of the cells (identity unless PMC_CELL_SHUFFLE=g asks for groups of 2^g cells to be scattered)
+        // device numbering of the cells: depth-first order of the tree, children in child order (tuning aids:
+        // PMC_CELL_ORDER=ref keeps the caller's numbering -- breadth-first by level in SKIRT; PMC_CELL_SHUFFLE=g scatters
+        // groups of 2^g cells of that numbering over the table)
         {
             const int n = g.num_cells;
+            T.perm.assign(n, -1);
+            const char* order = getenv("PMC_CELL_ORDER");
             int gb = -1;
             if (const char* env = getenv("PMC_CELL_SHUFFLE")) gb = atoi(env);
-            T.perm.resize(n);
-            if (gb < 0 || gb > 16)
-            {
-                T.cellSlots = n;
-                for (int m = 0; m < n; ++m) T.perm[m] = m;
-            }
-            else
+            if (gb >= 0 && gb <= 16)
             {
                 const int groupSize = 1 << gb;
                 const int numGroups = (n + groupSize - 1) / groupSize;
@@ -249,6 +247,32 @@ namespace
                 }
                 T.cellSlots = numGroups * groupSize;
                 for (int m = 0; m < n; ++m) T.perm[m] = where[m >> gb] * groupSize + (m & (groupSize - 1));
+            }
+            else if (order && !strcmp(order, "ref"))
+            {
+                T.cellSlots = n;
+                for (int m = 0; m < n; ++m) T.perm[m] = m;
+            }
+            else
+            {
+                T.cellSlots = n;
+                int next = 0;
+                std::vector<int> stack{0};
+                while (!stack.empty())
+                {
+                    const int id = stack.back();
+                    stack.pop_back();
+                    const int first = g.node_first_child[id];
+                    if (first < 0)
+                    {
+                        const int m = g.node_cell[id];
+                        if (m < 0 || m >= n || T.perm[m] >= 0) return fail(PMC_ERR_INVALID, "octree leaf without a valid cell index");
+                        T.perm[m] = next++;
+                    }
+                    else
+                        for (int l = 7; l >= 0; --l) stack.push_back(first + l);
+                }
+                if (next != n) return fail(PMC_ERR_INVALID, "octree leaves and cells do not match");
             }
             T.cellExt.assign(T.cellSlots, -1);
             for (int m = 0; m < n; ++m) T.cellExt[T.perm[m]] = m;
@@ -266,6 +290,18 @@ namespace
             const uint32_t e = uint32_t(maxLevel - g.node_level[id]);
             return g.node_first_child[id] < 0 ? (e | (uint32_t(T.perm[g.node_cell[id]]) << 4))
                                               : (e | (uint32_t(internalIndex[id]) << 4) | PMC_LINK_NODE);
+        };
+        // the link of a cell record through a wall: as linkOf, but an internal node whose children are all leaves with
+        // consecutive device indices in child order becomes an octet link (the walk picks the child without a load)
+        auto wallLinkOf = [&](int id) -> uint32_t {
+            if (id < 0 || g.node_first_child[id] < 0) return linkOf(id);
+            const int first = g.node_first_child[id];
+            for (int l = 0; l < 8; ++l)
+                if (g.node_first_child[first + l] >= 0) return linkOf(id);
+            const int base = T.perm[g.node_cell[first]];
+            for (int l = 1; l < 8; ++l)
+                if (T.perm[g.node_cell[first + l]] != base + l) return linkOf(id);
+            return uint32_t(maxLevel - g.node_level[id]) | (uint32_t(base) << 4) | PMC_LINK_OCTET;
         };
         T.rootLink = linkOf(0);
         // top-down search table (pmc_walk.inc topDown): per cell of the regular grid of level Lc the node of level Lc
@@ -314,7 +350,7 @@ namespace
         const int numCells = g.num_cells;
         const int cellSlots = T.cellSlots;
         T.leaves.assign(cellSlots, LeafRec{});
-        T.axis.assign(3 * size_t(cellSlots), AxisRec{});
+        T.cells.assign(size_t(cellSlots), CellRec{});
         T.internals.assign(numInternal, NodeRec{});
         T.nbrStart.assign(6 * size_t(cellSlots) + 1, 0);
         T.nbrList.clear();
@@ -345,14 +381,13 @@ namespace
             LeafRec& rec = T.leaves[dev];
             rec.code = code(id);
             rec.density = density[m];
+            CellRec& hot = T.cells[dev];
+            hot.density = density[m];
             for (int wall = 0; wall < 6; ++wall)
             {
-                const int axis = wall >> 1, side = wall & 1;
                 // the leaf across the wall (same size or coarser), or the same-size internal node (finer neighbours: the walk
-                // descends from it by the index bits of its position), or "outside"
-                AxisRec& hot = T.axis[size_t(axis) * cellSlots + dev];
-                hot.density = density[m];
-                hot.link[side] = linkOf(covering(id, wall));
+                // picks the child by the index bits of its position), or "outside"
+                hot.link[wall] = wallLinkOf(covering(id, wall));
                 // the reference's neighbour list of this leaf, in device numbering
                 T.nbrStart[6 * size_t(dev) + wall] = (int32_t)T.nbrList.size();
                 for (int qq = g.nbr_start[6 * size_t(id) + wall]; qq < g.nbr_start[6 * size_t(id) + wall + 1]; ++qq)
@@ -586,15 +621,15 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if ((rc = buildTree(g, scene->medium.number_density, T))) return bail(rc);
         D.lmax = T.lmax;
         D.root_link = T.rootLink;
-        if (T.cellSlots >= (1 << 24) || T.internals.size() > (size_t(1) << 26))
-            return bail(fail(PMC_ERR_UNSUPPORTED, "octree with 2^24 cells or more (24-bit table index arithmetic, 27-bit link index)"));
+        if (size_t(T.cellSlots) > PMC_LINK_MAX_INDEX || T.internals.size() > PMC_LINK_MAX_INDEX)
+            return bail(fail(PMC_ERR_UNSUPPORTED, "octree with 2^26 cells or nodes or more (26-bit link index)"));
         D.tab_stride_bytes = 8u * uint32_t(T.tabn);
         D.fine_scale[0] = double(1 << T.lmax) / (g.xmax - g.xmin);
         D.fine_scale[1] = double(1 << T.lmax) / (g.ymax - g.ymin);
         D.fine_scale[2] = double(1 << T.lmax) / (g.zmax - g.zmin);
         if ((rc = ctx->upload(T.table.data(), T.table.size(), &D.coord_tab))) return bail(rc);
         if ((rc = ctx->upload(T.leaves.data(), T.leaves.size(), &D.leaves))) return bail(rc);
-        if ((rc = ctx->upload(T.axis.data(), T.axis.size(), &D.axis_tab))) return bail(rc);
+        if ((rc = ctx->upload(T.cells.data(), T.cells.size(), &D.cell_tab))) return bail(rc);
         if ((rc = ctx->upload(T.internals.data(), T.internals.size(), &D.nodes))) return bail(rc);
         D.coarse_level = T.coarseLevel;
         if ((rc = ctx->upload(T.coarse.data(), T.coarse.size(), &D.coarse_tab))) return bail(rc);
@@ -851,7 +886,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     }
     hipStream_t st = ctx->stream;
     unsigned long long* ctr = D.counters;
-    float walkMs = 0, transMs = 0;
+    float walkMs = 0, transMs = 0, peelMs = 0;
+    const bool serialWalks = getenv("PMC_SERIAL_WALKS") != nullptr;  // tuning aid: peel-off and propagation kernels one after the other
     int generations = 0;
     // ---- slot groups: group g owns the slots [base[g], base[g] + size[g]) and the stream groupStream[g].  The
     // generations of different groups are independent (histories come from one shared cursor), so while the host
@@ -895,7 +931,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 // the walks of the generation: one peel-off kernel per observer on the group's side stream, next to the
                 // propagation kernel on the group's stream (they touch different task records and result fields)
                 hipStream_t sp = ctx->peelStream[g];
-                if (getenv("PMC_SERIAL_WALKS")) sp = sg;  // tuning aid: peel-off and propagation kernels one after the other
+                if (serialWalks) sp = sg;
                 HIP_TRY(hipStreamWaitEvent(sp, ctx->evA[g], 0));
                 for (int i = 0; i < D.num_instruments; ++i)
                     if (!D.inst[i].same_observer)
@@ -951,6 +987,11 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             {
                 HIP_TRY(hipEventElapsedTime(&ms, ctx->evA[g], ctx->evB[g]));
                 walkMs += ms;
+                if (serialWalks && D.grid_kind == PMC_GRID_OCTREE)
+                {
+                    HIP_TRY(hipEventElapsedTime(&ms, ctx->evA[g], ctx->evJoin[g]));
+                    peelMs += ms;
+                }
             }
             HIP_TRY(hipEventElapsedTime(&ms, ctx->evB[g], ctx->evC[g]));
             transMs += ms;
@@ -972,6 +1013,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     HIP_TRY(hipEventElapsedTime(&ctx->totalMs, ctx->evStart, ctx->evStop));
     ctx->walkMs = walkMs;
     ctx->transitionMs = transMs;
+    if (serialWalks && getenv("PMC_TIMING_DUMP"))
+        fprintf(stderr, "PMC_TIMING peel %.2f ms prop %.2f ms transition+launch %.2f ms segment %.2f ms\n", peelMs, walkMs - peelMs, transMs, ctx->totalMs);
     ctx->generations = generations;
     ctx->timed = true;
     return PMC_OK;
@@ -1096,6 +1139,12 @@ int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out)
             fprintf(stderr, "PMC_PROFILE %s phases (wave cycles): gather %llu tau+position %llu descent %llu walls %llu inside+exit %llu "
                             "service-finish+claim %llu service-loads %llu loop %llu\n", k ? "prop" : "peel", t[0], t[1], t[2], t[3], t[4], t[5],
                     t[6], t[7]);
+        }
+        for (int k = 0; k < 2; ++k)
+        {
+            const unsigned long long* c = host + 104 + 8 * k;
+            fprintf(stderr, "PMC_PROFILE %s census (lane events): literal-algorithm steps %llu, edge %llu, descents %llu over %llu levels, octet links %llu, "
+                            "hit %llu, exit %llu\n", k ? "prop" : "peel", c[0], c[2], c[3], c[4], c[5], c[6], c[7]);
         }
         fprintf(stderr, "PMC_PROFILE transition (wave cycles): stage %llu mode-load %llu cycle-tail %llu append %llu loads+detect %llu scatter %llu start-cycle %llu flush %llu\n",
                 host[40], host[41], host[42], host[43], host[44], host[45], host[46], host[47]);

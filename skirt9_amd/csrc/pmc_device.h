@@ -1,8 +1,8 @@
 // pmc_device.h -- device-side data layout of the MI355X photon-packet engine (shared by host API and kernels).
 //
 // HBM layout (read-only during a segment, replicated per GPU):
-//   octree cells    AxisRec[3][num_cells] the hot table of the walk step (16 B per cell and exit axis: density + the two links
-//                                        of that axis), LeafRec[num_cells] the cold one (box code, density)
+//   octree cells    CellRec[num_cells]   the hot table of the walk step (32 B per cell: density + the six wall links), cells
+//                                        in depth-first order of the tree; LeafRec[num_cells] the cold one (box code, density)
 //   octree nodes    NodeRec[num_internal] 64-byte record per non-leaf node: box code + 8 child links (descent only)
 //   coord table     double[3][2^Lmax+1]  the reference's wall coordinates per axis and dyadic index; staged in LDS
 //   neighbour CSR   int32                the reference's per-wall neighbour lists of every leaf, in the reference's
@@ -23,24 +23,31 @@
 #define PMC_MAX_LEVEL 12
 #define PMC_STAT_CAP 48     // per-history contribution list capacity per instrument (FluxRecorder statistics)
 
-// link word (uint32): bits 0-3 size exponent e of the target box (its edge spans 2^e finest cells), bits 4-30 index,
-// bit 31 clear: leaf cell m = index; bit 31 set: internal node (NodeRec index); PMC_LINK_NONE: outside the grid
+// link word (uint32): bits 0-3 size exponent e of the target box (its edge spans 2^e finest cells), bits 4-29 index,
+// bits 30-31 kind: 0 leaf cell (device index), PMC_LINK_NODE internal node (NodeRec index), PMC_LINK_OCTET internal node
+// whose eight children are all leaves (index = device index of child 0; the children are consecutive cells in child order,
+// e = exponent of the NODE); PMC_LINK_NONE: outside the grid (test it first: its bit 30 is set)
 #define PMC_LINK_NONE 0x7FFFFFFFu
 #define PMC_LINK_NODE 0x80000000u
-#define PMC_LINK_MAX_INDEX ((1u << 27) - 2u)
+#define PMC_LINK_OCTET 0x40000000u
+#define PMC_LINK_INDEX_MASK 0x3FFFFFFu
+#define PMC_LINK_MAX_INDEX ((1u << 26) - 2u)
 
-// Octree cells.  A walk step leaves its cell through a wall of ONE axis and needs the cell's density and the link
-// through that wall: both come with a single 16-byte gather from the HOT table AxisRec[3][num_cells], which is split
-// by exit axis so that four consecutive cells -- siblings, the likely next cells of a walk -- share a 64-byte sector.
-// A link names the leaf that covers the whole wall (same size or coarser), or the same-size internal node whose
-// children share the wall (finer neighbours): the walk then descends by the index bits of its position, one 4-byte
-// gather per level.  LeafRec is the COLD per-cell record (start of a walk, undecided steps).
-struct AxisRec
+// Octree cells.  A walk step leaves its cell through ONE wall and needs the cell's density and the link through that
+// wall: the step gathers the cell's HOT record CellRec (32 bytes: two 16-byte loads from one sector, issued as soon as the
+// cell is known -- before the arithmetic of the step that enters it -- so that the memory round trip of a step overlaps
+// with the arithmetic of the previous one).  Cells are numbered in depth-first order of the tree: siblings are consecutive
+// (four records per 128-byte line), and spatially close cells of any level are close in the table.
+// A link names the leaf that covers the whole wall (same size or coarser); or, when finer neighbours share the wall, the
+// same-size internal node: if its children are all leaves (PMC_LINK_OCTET) the child is picked by the index bits of the
+// position without any load, otherwise (PMC_LINK_NODE) the walk descends with one 4-byte gather per level.
+// LeafRec is the COLD per-cell record (start of a walk, undecided steps).
+struct CellRec
 {
-    double   density;   // number density n[m] (the same in the three tables)
-    uint32_t link[2];   // through the lower / upper wall of this axis
+    double   density;   // number density n[m]
+    uint32_t link[6];   // through wall 2 * axis + side (side 0: lower wall, 1: upper wall)
 };
-static_assert(sizeof(AxisRec) == 16, "AxisRec must be 16 bytes");
+static_assert(sizeof(CellRec) == 32, "CellRec must be 32 bytes");
 
 struct LeafRec
 {
@@ -186,14 +193,14 @@ struct DevScene
     int32_t coarse_level;        // octree: level Lc = min(lmax, 6) of the top-down search table
     const uint32_t* coarse_tab;  // [2^Lc][2^Lc][2^Lc] (z, y, x): link of the node at level <= Lc that covers the coarse cell
     const LeafRec* leaves;
-    const AxisRec* axis_tab;     // [3][num_cells]: the walk step's gather
+    const CellRec* cell_tab;     // [cell_slots]: the walk step's gather
     const NodeRec* nodes;
     uint32_t root_link;
     const int32_t* nbr_start;    // [6*num_cells + 1]
     const int32_t* nbr_list;     // leaf cell indices
     int32_t num_cells;
-    // octree: the device tables number the cells in their own order (pmc_api.hip buildTree: sibling groups scattered
-    // over the table); cell_ext[device index] = the caller's cell index m, cell_slots = entries per device table
+    // octree: the device tables number the cells in their own order (pmc_api.hip buildTree: depth-first order of the
+    // tree); cell_ext[device index] = the caller's cell index m, cell_slots = entries per device table
     const int32_t* cell_ext;
     int32_t cell_slots;
     // Voronoi (pmc_grid::site ...): site positions as double4-aligned records {x, y, z, number density}, so that one
