@@ -31,11 +31,10 @@ extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlo
                                     hipStream_t stream);
 extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, int cursor, uint64_t seed, int grid,
                                     size_t ldsBytes, hipStream_t stream);
-extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
-                                          uint64_t seed, int maxBlocks, size_t ldsBytes, hipStream_t stream);
-extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
-                                      uint64_t first, uint64_t count, uint64_t seed, int initial, int grid, size_t ldsBytes,
-                                      hipStream_t stream);
+extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, uint64_t seed, int maxBlocks,
+                                          size_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int group, uint64_t first, uint64_t count,
+                                      uint64_t seed, int initial, int maxBlocks, size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchTrace(int slot, int gridKind, int wide, int uniform, const double r[3], const double k[3],
                                      const double* kdev, int32_t* m, double* ds, int32_t cap, int32_t* n, size_t ldsBytes,
                                      hipStream_t stream);
@@ -442,8 +441,8 @@ namespace
         int32_t** tints[] = {&K.cell, &K.cijk};
         for (int32_t** d : tints)
             if ((rc = ctx->allocate<int32_t>(nt, d, false, &own))) return rc;
-        // launch lists: per group PMC_LAUNCH_SHARDS regions whose capacities add up to at most group size + 65536
-        if ((rc = ctx->allocate<int32_t>(size_t(n) + size_t(PMC_MAX_GROUPS) * 65536, &K.launchList, false, &own))) return rc;
+        // ended-history counts per tile of 64 slots (padded: the scan reads and writes 16 bytes at a time)
+        if ((rc = ctx->allocate<uint32_t>(size_t(n) / 64 + 64, &K.endedCount, true, &own))) return rc;
         if ((rc = ctx->allocate<uint32_t>(nt, &K.bits, false, &own))) return rc;
     if (ctx->dev.grid_kind == PMC_GRID_OCTREE && (rc = ctx->allocate<uint64_t>(nt, &K.pidx, false, &own))) return rc;
         A.num_slots = n;
@@ -778,6 +777,8 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     transDoubles += sedDoubles;
     D.lds_hot_off = transDoubles;
     transDoubles += 2 * 256;  // hot-bin table (pmc_transition.inc HOT_BINS keys + values)
+    D.lds_stat_off = transDoubles;
+    transDoubles += 6 * 128;  // hot-bin table of the statistics (pmc_transition.inc STAT_BINS keys + 5 values each)
     D.lds_sort_off = transDoubles;
     transDoubles += (64 + 2 * 1024 + 8) / 2;  // integer scratch: regrouping arrays and list-append counters
     D.lds_total_transition = transDoubles;
@@ -806,8 +807,10 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if (D.grid_kind == PMC_GRID_OCTREE)
         {
             int peelPerCU = pmcWalkBlocksPerCU(D.grid_kind, 1, ctx->wide, pmcPeelBlock(), ctx->walkLds);
-            if (peelPerCU < 1) peelPerCU = 1;
-            if (const char* env = getenv("PMC_PEEL_BLOCKS_PER_CU")) peelPerCU = std::min(peelPerCU, std::max(1, atoi(env)));
+            // (one workgroup of 512 lanes per CU: with the pipelined step more resident waves only queue up in the memory
+            // system -- 1 / 2 / 3 per CU: 97 / 111 / 124 ms per 5e7 packets, profiles/README.md)
+            peelPerCU = std::min(std::max(peelPerCU, 1), 1);
+            if (const char* env = getenv("PMC_PEEL_BLOCKS_PER_CU")) peelPerCU = std::max(1, atoi(env));
             ctx->peelGrid = ctx->numCU * peelPerCU;
         }
     }
@@ -821,7 +824,6 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     if ((rc = ctx->allocate<double>(ctx->frameSize, &ctx->frames, true))) return bail(rc);
     D.frames = ctx->frames;
     if ((rc = ctx->allocate<unsigned long long>(PMC_NUM_COUNTERS, &D.counters, true))) return bail(rc);
-    if ((rc = ctx->allocate<unsigned int>(PMC_MAX_GROUPS * PMC_LAUNCH_SHARDS, &D.launch_count, true))) return bail(rc);
     *out = ctx;
     return PMC_OK;
 }
@@ -911,17 +913,12 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     HIP_TRY(hipMemsetAsync(ctr + 32, 0, 4 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(0, 0), 0, 8 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(ctx->evStart, st));
-    const int launchGrid = std::max(1, ctx->numCU * 4) / PMC_LAUNCH_SHARDS * PMC_LAUNCH_SHARDS + PMC_LAUNCH_SHARDS;
+    int launchBlocks = ctx->numCU * 4;  // persistent launch workgroups, as the transition kernel's
+    if (const char* env = getenv("PMC_LAUNCH_BLOCKS_PER_CU")) launchBlocks = ctx->numCU * std::max(1, atoi(env));
     int transitionBlocks = ctx->numCU * 4;  // persistent transition workgroups (tables staged once per workgroup)
     if (const char* env = getenv("PMC_TRANSITION_BLOCKS_PER_CU")) transitionBlocks = ctx->numCU * std::max(1, atoi(env));
-    // (a multiple of the shard count, so that tile t always appends to launch-list shard t mod shards)
-    transitionBlocks = (transitionBlocks + PMC_LAUNCH_SHARDS - 1) / PMC_LAUNCH_SHARDS * PMC_LAUNCH_SHARDS;
     auto enqueue = [&](int g, bool initial) -> int {
         hipStream_t sg = ctx->groupStream[g];
-        // the group's launch list: shard regions of shardCap entries from listBase
-        const int numBlocks = (size[g] + PMC_TRANSITION_ALIGN - 1) / PMC_TRANSITION_ALIGN;
-        const int shardCap = (numBlocks + PMC_LAUNCH_SHARDS - 1) / PMC_LAUNCH_SHARDS * PMC_TRANSITION_ALIGN;
-        const int listBase = base[g] + g * 65536;
         if (!initial)
         {
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(g, 0), 0, 8 * sizeof(unsigned long long), sg));  // task cursors
@@ -946,18 +943,14 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             haveWalk[g] = true;
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_LIVE(g), 0, sizeof(unsigned long long), sg));
-            HIP_TRY(hipMemsetAsync(D.launch_count + g * PMC_LAUNCH_SHARDS, 0, PMC_LAUNCH_SHARDS * sizeof(unsigned int), sg));
-            HIP_TRY(pmcLaunchTransition(ctx->slot, D.grid_kind, base[g], size[g], g, listBase, shardCap, seed, transitionBlocks,
-                                        ctx->transitionLds, sg));
-            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], g, listBase, shardCap, first, count, seed, 0, launchGrid,
-                                    ctx->transitionLds, sg));
+            HIP_TRY(pmcLaunchTransition(ctx->slot, D.grid_kind, base[g], size[g], g, seed, transitionBlocks, ctx->transitionLds, sg));
+            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], g, first, count, seed, 0, launchBlocks, ctx->transitionLds, sg));
         }
         else
         {
             if (g > 0) HIP_TRY(hipStreamWaitEvent(sg, ctx->evStart, 0));
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
-            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], g, listBase, shardCap, first, count, seed, 1,
-                                    (size[g] + 255) / 256, ctx->transitionLds, sg));
+            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], g, first, count, seed, 1, (size[g] + 255) / 256, ctx->transitionLds, sg));
         }
         HIP_TRY(hipEventRecord(ctx->evC[g], sg));
         HIP_TRY(hipMemcpyAsync(ctx->pinned + g, ctr + PMC_CTR_LIVE(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));

@@ -21,7 +21,8 @@
 #define PMC_MAX_INSTRUMENTS 4
 #define PMC_MAX_CONTEXTS 8  // scene slots in constant memory (live contexts per process and device)
 #define PMC_MAX_LEVEL 12
-#define PMC_STAT_CAP 48     // per-history contribution list capacity per instrument (FluxRecorder statistics)
+#define PMC_STAT_CAP 48     // per-history list capacity per instrument: DISTINCT pixels a history contributes to (FluxRecorder
+                            // statistics); a multiple of 4
 
 // link word (uint32): bits 0-3 size exponent e of the target box (its edge spans 2^e finest cells), bits 4-29 index,
 // bits 30-31 kind: 0 leaf cell (device index), PMC_LINK_NODE internal node (NodeRec index), PMC_LINK_OCTET internal node
@@ -143,11 +144,12 @@ struct TaskArrays
                                             // their direction is the observer's)
     int32_t* cijk;                          // Cartesian: cell indices i | j << 10 | k << 20; Voronoi: exit neighbour
     uint64_t* pidx;                         // octree: packed fine lower-corner indices of the first cell (Walk::P)
-    int32_t* launchList;                    // slots whose history has ended (consumed by the launch kernel): per slot group
-                                            // PMC_LAUNCH_SHARDS regions of shard_cap entries, counted by DevScene::launch_count
+    uint32_t* endedCount;                   // [num_slots / 64 + pad] per wave tile (64 consecutive slots): the histories that
+                                            // ended in the tile this generation (transition kernel); endedScanKernel turns the
+                                            // counts of a slot group into their exclusive prefix, from which the launch kernel
+                                            // derives the index of the history each of those slots takes up next
 };
 #define PMC_TASK_NONE 0xFFFFFFFFu
-#define PMC_LAUNCH_SHARDS 64
 
 #define PMC_MAX_SOURCES 8
 // one source of the source system: spatial sampling, luminosity per packet, wavelength sampling (pmc.h pmc_source)
@@ -242,14 +244,13 @@ struct DevScene
     double* frames;
     unsigned long long* counters;  // [PMC_NUM_COUNTERS]: [0..6] pmc_counter_values, [8] next history offset,
                                    // [11..31] profiling, [32 + 4 g ..] work counters of slot group g (PMC_CTR_*)
-    unsigned int* launch_count;    // [PMC_MAX_GROUPS][PMC_LAUNCH_SHARDS] entries in the shards of the launch lists
     SlotArrays slots;
     TaskArrays tasks;
     // ---- LDS carve-up (in doubles from the start of dynamic LDS; no kernel has static LDS, so that the octree
     //      coordinate table sits at LDS address 0 in all of them)
     int32_t lds_grid_len;          // all kernels: grid tables at offset 0
     int32_t lds_dust_off;          // transition/launch kernels: dust tables (the walk kernel keeps sigma_ext after the grid)
-    int32_t lds_src_off, lds_sed_off, lds_sed_len, lds_hot_off, lds_sort_off, lds_total_transition, lds_total_walk;
+    int32_t lds_src_off, lds_sed_off, lds_sed_len, lds_hot_off, lds_stat_off, lds_sort_off, lds_total_transition, lds_total_walk;
     int32_t dust_in_lds;
 };
 
@@ -261,6 +262,8 @@ struct DevScene
 // kernel, k = 1 + observer: the peel-off kernel of that observer)
 #define PMC_CTR_LIVE(g) (35 + 4 * (g))
 #define PMC_CTR_TASK(g, k) (64 + 8 * (g) + (k))
+// per slot group g: offset of the first history the group's ended slots take up this generation (endedScanKernel)
+#define PMC_CTR_HBASE(g) (120 + (g))
 #define PMC_MAX_GROUPS 4
 #define PMC_TRANSITION_ALIGN 1024  // slot groups start at multiples of the transition kernel's workgroup size
 

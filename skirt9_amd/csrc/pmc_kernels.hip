@@ -57,16 +57,17 @@
                                 // several hundred instructions whatever the number of lanes it serves)
 #endif
 #ifndef PMC_PEEL_REFILL
-    #define PMC_PEEL_REFILL 16  // octree peel-off kernel: waiting lanes that trigger a (cheap) service round
+    #define PMC_PEEL_REFILL 32  // octree peel-off kernel: waiting lanes that trigger a service round (16 / 24 / 32 with the
+                                // propagation kernel at 24 / 32 / 40: 413 / 387 / 376 ms per 5e7 packets, profiles/README.md)
 #endif
 #ifndef PMC_PROP_REFILL
-    #define PMC_PROP_REFILL 24  // octree propagation kernel: likewise (its round includes the pass-1 -> pass-2 sampling)
+    #define PMC_PROP_REFILL 40  // octree propagation kernel: likewise (its round includes the pass-1 -> pass-2 sampling)
 #endif
 #ifndef PMC_PEEL_BLOCK
     #define PMC_PEEL_BLOCK 512  // lanes per workgroup of the peel-off kernel (one coordinate table in LDS per workgroup)
 #endif
 #ifndef PMC_PEEL_MIN_WAVES
-    #define PMC_PEEL_MIN_WAVES 6  // waves per SIMD the peel-off kernel's register budget must allow (<= 80 VGPRs; it uses 65,
+    #define PMC_PEEL_MIN_WAVES 6  // waves per SIMD the peel-off kernel's register budget must allow (<= 80 VGPRs; it uses 75,
                                   // and must not spill: see treeSlowStep)
 #endif
 #ifndef PMC_PROP_MIN_WAVES
@@ -76,7 +77,8 @@
     #define PMC_WALK_MIN_WAVES 1  // waves per SIMD the walk kernel's register budget must allow
 #endif
 #ifndef PMC_TRANSITION_MIN_WAVES
-    #define PMC_TRANSITION_MIN_WAVES 1  // likewise for the transition and launch kernels
+    #define PMC_TRANSITION_MIN_WAVES 2  // likewise for the transition and launch kernels (256 registers: two waves per SIMD; left to
+                                        // itself the compiler takes 262 and halves the occupancy)
 #endif
 #ifndef PMC_VORO_PAIRS
     #define PMC_VORO_PAIRS 1  // Voronoi walk reads the per-(cell, neighbour) table DevScene::vpair instead of index -> site
@@ -103,6 +105,7 @@ namespace
     enum Mode : int { MODE_PASS1 = 0, MODE_PASS2 = 1, MODE_PEEL = 2, MODE_NONE = 3 };
     enum Grid : int { GRID_CART = PMC_GRID_CARTESIAN, GRID_TREE = PMC_GRID_OCTREE, GRID_VORO = PMC_GRID_VORONOI };
     constexpr int MODE_ALIVE = 1 << 5;
+    constexpr int MODE_ENDED = 1 << 6;  // the history of the slot has ended: the launch kernel takes up the next one
 
     // ------------------------------------------------------------------------------------------------
     struct Rng
@@ -282,40 +285,39 @@ extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBas
     return hipGetLastError();
 }
 
-// transitions of the slots [slotBase, slotBase + numSlots) of slot group `group`; ended histories go to the group's
-// sharded launch list at listBase (shardCap entries per shard)
-extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
-                                          uint64_t seed, int maxBlocks, size_t ldsBytes, hipStream_t stream)
+// transitions of the slots [slotBase, slotBase + numSlots) of slot group `group`, followed by the scan of the group's
+// ended-history counts (the launch kernel's history indices)
+extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, uint64_t seed, int maxBlocks,
+                                          size_t ldsBytes, hipStream_t stream)
 {
     const int block = PMC_TRANSITION_BLOCK;
     const int grid = std::max(1, std::min((numSlots + block - 1) / block, maxBlocks));
     if (gridKind == PMC_GRID_OCTREE)
-        hipLaunchKernelGGL(transitionKernel<GRID_TREE>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group,
-                           listBase, shardCap, seed);
+        hipLaunchKernelGGL(transitionKernel<GRID_TREE>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group, seed);
     else if (gridKind == PMC_GRID_VORONOI)
-        hipLaunchKernelGGL(transitionKernel<GRID_VORO>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group,
-                           listBase, shardCap, seed);
+        hipLaunchKernelGGL(transitionKernel<GRID_VORO>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group, seed);
     else
-        hipLaunchKernelGGL(transitionKernel<GRID_CART>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group,
-                           listBase, shardCap, seed);
+        hipLaunchKernelGGL(transitionKernel<GRID_CART>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group, seed);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(endedScanKernel, dim3(1), dim3(1024), 0, stream, slot, slotBase, numSlots, group);
     return hipGetLastError();
 }
 
-// launches of new histories into the slots whose history ended (initial: into all slots of the group); grid must be a
-// multiple of PMC_LAUNCH_SHARDS unless initial
-extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int group, int listBase, int shardCap,
-                                      uint64_t first, uint64_t count, uint64_t seed, int initial, int grid, size_t ldsBytes,
-                                      hipStream_t stream)
+// launches of new histories into the slots of the group whose history ended (initial: into all slots of the group)
+extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int group, uint64_t first, uint64_t count,
+                                      uint64_t seed, int initial, int maxBlocks, size_t ldsBytes, hipStream_t stream)
 {
+    const int grid = std::max(1, std::min((numSlots + 255) / 256, maxBlocks));
     if (gridKind == PMC_GRID_OCTREE)
-        hipLaunchKernelGGL(launchKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, listBase,
-                           shardCap, first, count, seed, initial);
+        hipLaunchKernelGGL(launchKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, first, count, seed,
+                           initial);
     else if (gridKind == PMC_GRID_VORONOI)
-        hipLaunchKernelGGL(launchKernel<GRID_VORO>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, listBase,
-                           shardCap, first, count, seed, initial);
+        hipLaunchKernelGGL(launchKernel<GRID_VORO>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, first, count, seed,
+                           initial);
     else
-        hipLaunchKernelGGL(launchKernel<GRID_CART>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, listBase,
-                           shardCap, first, count, seed, initial);
+        hipLaunchKernelGGL(launchKernel<GRID_CART>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, first, count, seed,
+                           initial);
     return hipGetLastError();
 }
 
