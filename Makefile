@@ -19,19 +19,19 @@ skirt9_amd/lib/libskirthost.so: $(HOST_LIB_SRC) $(HOST_HDR)
 
 skirt9_amd/lib/libpmc.so: $(wildcard skirt9_amd/csrc/*.hip) $(wildcard skirt9_amd/csrc/*.h) $(wildcard skirt9_amd/csrc/*.inc) $(wildcard include/*.h)
 	@mkdir -p skirt9_amd/lib
-	$(HIPCC) $(HIPFLAGS) -shared $(wildcard skirt9_amd/csrc/*.hip) -o $@
+	$(HIPCC) $(HIPFLAGS) -shared $(wildcard skirt9_amd/csrc/*.hip) -lrccl -o $@
 
 # tuning aid: the same engine with in-kernel cycle stamps (PMC_LIBRARY=.../libpmc_prof.so PMC_PROFILE_DUMP=1)
 profile-lib: skirt9_amd/lib/libpmc_prof.so
 skirt9_amd/lib/libpmc_prof.so: $(wildcard skirt9_amd/csrc/*.hip) $(wildcard skirt9_amd/csrc/*.h) $(wildcard skirt9_amd/csrc/*.inc) $(wildcard include/*.h)
 	@mkdir -p skirt9_amd/lib
-	$(HIPCC) $(HIPFLAGS) -DPMC_PROFILE -DPMC_PROFILE_STAMPS -shared $(wildcard skirt9_amd/csrc/*.hip) -o $@
+	$(HIPCC) $(HIPFLAGS) -DPMC_PROFILE -DPMC_PROFILE_STAMPS -shared $(wildcard skirt9_amd/csrc/*.hip) -lrccl -o $@
 
 # event census of the walk kernels without the time stamps (PMC_LIBRARY=.../libpmc_census.so PMC_PROFILE_DUMP=1)
 census-lib: skirt9_amd/lib/libpmc_census.so
 skirt9_amd/lib/libpmc_census.so: $(wildcard skirt9_amd/csrc/*.hip) $(wildcard skirt9_amd/csrc/*.h) $(wildcard skirt9_amd/csrc/*.inc) $(wildcard include/*.h)
 	@mkdir -p skirt9_amd/lib
-	$(HIPCC) $(HIPFLAGS) -DPMC_PROFILE -shared $(wildcard skirt9_amd/csrc/*.hip) -o $@
+	$(HIPCC) $(HIPFLAGS) -DPMC_PROFILE -shared $(wildcard skirt9_amd/csrc/*.hip) -lrccl -o $@
 
 skirt9_amd/lib/skirt_mi355x: skirt9_amd/host/main.cpp skirt9_amd/lib/libskirthost.so skirt9_amd/lib/libpmc.so
 	$(CXX) $(CXXFLAGS) skirt9_amd/host/main.cpp -Lskirt9_amd/lib -lskirthost -lpmc -pthread -Wl,-rpath,'$$ORIGIN' -o $@

@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def pmc_traffic(packets_per_step):
-    """HBM bytes the walk kernel moves in one step (all its launches), from the newest committed PMC summary
+    """(bytes, source file) -- HBM bytes the walk kernels move in one step (all their launches), from the newest committed PMC summary
     profiles/r*_pmc_hbm.csv: FETCH_SIZE + WRITE_SIZE (KiB, separate rocprofv3 --pmc passes over one step of 2e7
     packets of this workload; tools/run_profile_set.sh, tools/pmc_hbm_summary.py), scaled by the packet count.  The
     kernel's reads are 4- and 8-byte gathers (64-byte fabric requests), so the gfx950 x2 correction for wide coalesced
@@ -46,12 +46,12 @@ def pmc_traffic(packets_per_step):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.csv")),
                    key=lambda f: [int(x) for x in re.findall(r"[0-9]+", os.path.basename(f))])
     if not files:
-        return None
+        return None, None
     kib = 0.0
     for row in csv.DictReader(open(files[-1])):
-        if row["kernel"] == "walkKernel":
+        if row["kernel"] in ("walkKernel", "walkPeelKernel", "walkPropKernel"):
             kib += float(row["sum_KiB_per_step_of_2e7_packets"])
-    return kib * 1024.0 / 2e7 * packets_per_step if kib else None
+    return (kib * 1024.0 / 2e7 * packets_per_step if kib else None), os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(ski_path=SKI, input_dir=None, packets_per_core=100000):
@@ -109,6 +109,11 @@ def main():
     ap.add_argument("--store-radiation-field", action="store_true",
                     help="run the same workload with RadiationFieldOptions storeRadiationField=true (the RF flavour of the "
                          "walk kernel: one exp, one lnmean and one f64 atomic more per path segment); not the headline number")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --packets is the TOTAL per step, split over the ranks by history range (e.g. "
+                         "--config 4 --packets 1e9 --gpus 8 = BASELINE configs[3]); default: weak scaling, --packets per GPU")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the second measurement of the default run (the same octree with a uniform-box source)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -139,7 +144,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     P = int(args.packets)
-    total_per_step = P * world
+    total_per_step = P if args.strong else P * world
     if world > 1:
         os.environ.setdefault("SKH_THREADS", str(max(1, (os.cpu_count() or 1) // world)))  # host setup threads per rank
     if args.config == 3:
@@ -181,79 +186,125 @@ def main():
         rf_ski = os.path.join(tempfile.mkdtemp(prefix=f"bench_rf_r{rank}_"), os.path.basename(ski_path))
         open(rf_ski, "w").write(text.replace('storeRadiationField="false"', 'storeRadiationField="true"'))
         ski_path = rf_ski
-    sim = Simulation(ski_path, num_packets=total_per_step)
-    if args.config == 4:
-        sim.use_device_sampler(local_rank)  # setup-time density sampling of the particle medium on this rank's GPU
-    sim.setup()
-    eng = Engine(sim.scene, local_rank)
-    frames = torch.zeros(sim.frame_size, dtype=torch.float64, device=f"cuda:{local_rank}")
-    eng.bind_frames(frames.data_ptr(), frames.numel())
-    rf = None
-    if sim.radiation_field_size:
-        # the radiation field table in a torch tensor, so that the ranks can sum it onto ALL ranks over RCCL
-        # (MediumSystem::communicateRadiationField, MediumSystem.cpp:1304-1313)
-        rf = torch.zeros(sim.radiation_field_size, dtype=torch.float64, device=f"cuda:{local_rank}")
-        eng.bind_radiation_field(rf.data_ptr(), rf.numel())
-    seed = sim.seed
-
-    def step(index):
-        # static split of the segment's history range over the ranks; a fresh range per step
-        first = (index * world + rank) * P
-        eng.run_primary(first, P, seed)
-        eng.sync()
-        if world > 1:
-            if share:
-                dist.all_reduce(frames, op=dist.ReduceOp.SUM)  # (gloo has no GPU reduce)
-            else:
-                dist.reduce(frames, dst=0, op=dist.ReduceOp.SUM)
-            if rank != 0:
-                frames.zero_()  # rank 0 holds the sum so far; the others start the next segment from zero
-            if rf is not None:
-                dist.all_reduce(rf, op=dist.ReduceOp.SUM)
-                rf.zero_()      # (a benchmark step is a whole segment: what follows would consume the field here)
+    from skirt9_amd.distributed import history_range
+    from skirt9_amd.host import scene_head
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for w in range(args.warmup):
-        step(w)
-    frames.zero_()
-    eng.reset_counters()
-    fence()
-    t0 = time.perf_counter()
-    kernel_ms, timings = [], []
-    for s in range(args.steps):
-        step(args.warmup + s)
-        kernel_ms.append(eng.last_kernel_ms())   # HIP events around every walk-kernel launch of the segment, summed
-        timings.append(eng.last_timing())
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def measure(path, steps, warmup):
+        """sets the scene of ski file `path` up on this rank's GPU and times `steps` segments; returns the numbers of the
+        JSON line (rank 0) -- value, roofline inputs, counters"""
+        sim = Simulation(path, num_packets=total_per_step)
+        if args.config == 4:
+            sim.use_device_sampler(local_rank)  # setup-time density sampling of the particle medium on this rank's GPU
+        sim.setup()
+        eng = Engine(sim.scene, local_rank)
+        frames = torch.zeros(sim.frame_size, dtype=torch.float64, device=f"cuda:{local_rank}")
+        eng.bind_frames(frames.data_ptr(), frames.numel())
+        rf = None
+        if sim.radiation_field_size:
+            # the radiation field table in a torch tensor, so that the ranks can sum it onto ALL ranks over RCCL
+            # (MediumSystem::communicateRadiationField, MediumSystem.cpp:1304-1313)
+            rf = torch.zeros(sim.radiation_field_size, dtype=torch.float64, device=f"cuda:{local_rank}")
+            eng.bind_radiation_field(rf.data_ptr(), rf.numel())
+        seed = sim.seed
 
-    counters = eng.counters()
-    if rank == 0:
-        launches = max(1, args.steps)
-        V = counters["cell_visits"] / launches
-        U = counters["detector_updates"] / launches
+        def step(index):
+            # static split of the segment's history range over the ranks (pmc_history_range, SURVEY.md 8e); a fresh range
+            # of history indices per step.  The engine runs on its own streams: torch's work on the bound tensors (zero_,
+            # the previous reduce) must be complete before the segment starts.
+            torch.cuda.synchronize()
+            first, count = history_range(total_per_step, rank, world)
+            eng.run_primary(index * total_per_step + first, count, seed)
+            eng.sync()
+            if world > 1:
+                if share:
+                    dist.all_reduce(frames, op=dist.ReduceOp.SUM)  # (gloo has no GPU reduce)
+                else:
+                    dist.reduce(frames, dst=0, op=dist.ReduceOp.SUM)
+                if rank != 0:
+                    frames.zero_()  # rank 0 holds the sum so far; the others start the next segment from zero
+                if rf is not None:
+                    dist.all_reduce(rf, op=dist.ReduceOp.SUM)
+                    rf.zero_()      # (a benchmark step is a whole segment: what follows would consume the field here)
+
+        for w in range(warmup):
+            step(w)
+        frames.zero_()
+        eng.reset_counters()
+        fence()
+        t0 = time.perf_counter()
+        timings = []
+        for k in range(steps):
+            step(warmup + k)
+            t = eng.last_timing()
+            t["walk_ms"] = eng.last_kernel_ms()  # HIP events around every walk-kernel launch of the segment, summed
+            timings.append(t)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        counters = eng.counters()
+        grid = scene_head(sim).grid
+        result = {"elapsed": elapsed, "timings": timings, "counters": counters, "cells": int(grid.num_cells), "steps": steps,
+                  "packets_this_rank": history_range(total_per_step, rank, world)[1],
+                  "vnbr_mean": (grid.vnbr_start[grid.num_cells] / grid.num_cells) if args.config == 5 else None}
+        eng.close()
+        del frames, rf
+        return result
+
+    def roofline_of(m):
+        """algorithmic bytes of one step of this rank (V * bytes per visit + U * 8, V and U COUNTED by the kernels) over the
+        GPU time of the step's segment (HIP events on the engine's stream)"""
+        launches = max(1, m["steps"])
+        V = m["counters"]["cell_visits"] / launches
+        U = m["counters"]["detector_updates"] / launches
         bytes_per_visit = 20.0
         if args.config == 5:
             # Voronoi: a visit reads the cell's own record (site + density, 32 B) and, for each of its neighbours, the
             # neighbour index (4 B) and the neighbour's site (24 B) -- VoronoiMeshSnapshot.cpp:1096-1150; the mean
             # neighbour count is taken over the cells of the mesh (15.2 for tests/ski/cfg5.ski)
-            from skirt9_amd.host import scene_head
-            g = scene_head(sim).grid
-            nbar = g.vnbr_start[g.num_cells] / g.num_cells
-            bytes_per_visit = 32.0 + 28.0 * nbar
+            bytes_per_visit = 32.0 + 28.0 * m["vnbr_mean"]
+        n = max(1, m["packets_this_rank"])
         bytes_per_launch = bytes_per_visit * V + 8.0 * U
-        walk_ms_sum = sum(kernel_ms) / len(kernel_ms)
-        mean_ms = sum(t["total_ms"] for t in timings) / len(timings)
+        mean_ms = sum(t["total_ms"] for t in m["timings"]) / len(m["timings"])
         achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
-        value = total_per_step * args.steps / elapsed
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "kernel_ms": mean_ms, "segment_ms": mean_ms,
+                "walk_kernel_ms_sum": sum(t["walk_ms"] for t in m["timings"]) / len(m["timings"]),
+                "transition_kernel_ms": sum(t["transition_ms"] for t in m["timings"]) / len(m["timings"]),
+                "generations": sum(t["generations"] for t in m["timings"]) / len(m["timings"]),
+                "cell_visits_per_packet": V / n, "detector_updates_per_packet": U / n,
+                "rewalk_visits_per_packet": m["counters"]["rewalk_visits"] / launches / n,
+                "algorithmic_bytes_per_packet": bytes_per_launch / n, "algorithmic_bytes_per_visit": bytes_per_visit}
+
+    main_run = measure(ski_path, args.steps, args.warmup)
+    # the second source north_star names, measured in the same run on the same octree (default workload only): three steps
+    secondary = None
+    if args.config == 2 and args.source == "sersic" and not args.store_radiation_field and args.ski == SKI and not args.no_secondary:
+        text = open(SKI).read()
+        new = ('<UniformBoxGeometry minX="-10000 pc" maxX="10000 pc" minY="-10000 pc" maxY="10000 pc" '
+               'minZ="-1000 pc" maxZ="1000 pc"/>')
+        text, nsub = re.subn(r"<SersicGeometry[^>]*/>", new, text, count=1)
+        if nsub == 1:
+            upath = os.path.join(tempfile.mkdtemp(prefix=f"bench_u_r{rank}_"), "cfg2u.ski")
+            open(upath, "w").write(text)
+            secondary = measure(upath, 3, 1)
+
+    if rank == 0:
+        roof = roofline_of(main_run)
+        traffic, traffic_source = pmc_traffic(main_run["packets_this_rank"]) if (args.ski == SKI and args.source == "sersic" and args.config == 2) else (None, None)
+        roof["traffic"] = traffic
+        roof["traffic_source"] = (traffic_source + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build on a step of 2e7 packets, "
+                                  "scaled by the packet count (not collected in this run)") if traffic_source else None
+        roof["kernel"] = ("walkKernel<Voronoi>" if args.config == 5 else "walkPeelKernel + walkPropKernel (octree)") + \
+                         ": all launches of one step, overlapped on the slot groups' streams (denominator: segment_ms)"
+        value = total_per_step * args.steps / main_run["elapsed"]
         out = {
             "metric": "photon packets/s (whole node), 10^6-cell octree",
             "value": value,
@@ -261,43 +312,42 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * main_run["elapsed"] / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: " + ("Sersic" if args.source == "sersic" else "uniform-box")
-                                    + " source, 953688-cell PolicyTreeSpatialGrid octree (exp-disk dust, tau_z=1)"
+                                    + f" source, {main_run['cells']}-cell PolicyTreeSpatialGrid octree (exp-disk dust, tau_z=1)"
                                     if args.config == 2 else
-                                    "BASELINE configs[2]: Sersic source, 953688-cell octree, panchromatic 0.1-10 micron, 50-bin "
+                                    f"BASELINE configs[2]: Sersic source, {main_run['cells']}-cell octree, panchromatic 0.1-10 micron, 50-bin "
                                     "wavelength grid, tabulated dust mix (2102-point opacity table)"
                                     if args.config == 3 else
-                                    "BASELINE configs[4]: Sersic source, VoronoiMeshSpatialGrid of 10^5 sites (tools/make_sites.py "
+                                    f"BASELINE configs[4]: Sersic source, VoronoiMeshSpatialGrid of {main_run['cells']} sites (tools/make_sites.py "
                                     "--n 100000 --seed 1), panchromatic 0.1-10 micron, 20 bins, THREE FullInstruments 256^2"
                                     if args.config == 5 else
                                     "BASELINE configs[3]: Sersic source, dust imported from 10^6 smoothed particles "
-                                    "(tools/make_sph.py --n 1000000 --seed 1), 985979-cell density-policy octree")
+                                    f"(tools/make_sph.py --n 1000000 --seed 1), {main_run['cells']}-cell density-policy octree")
                                    + (", 0.55 micron" if args.config not in (3, 5) else "") + ", forced scattering, peel-off"
                                    + (" to one FullInstrument 512^2" if args.config != 5 else "")
                                    + " (components + statistics), " + os.path.relpath(args.ski, ROOT),
-                       "packets_per_step_per_gpu": P,
-                       "cells": 953688 if (args.ski == SKI or args.config == 3) else 985979 if args.config == 4
-                       else 100000 if args.config == 5 else None,
+                       "packets_per_step": total_per_step,
+                       "packets_per_step_per_gpu": total_per_step / world,
+                       "cells": main_run["cells"],
                        "store_radiation_field": bool(args.store_radiation_field),
                        "parallelism": f"history-range x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(P) if (args.ski == SKI and args.source == "sersic") else None,
-                         "kernel": "walkKernel<" + ("Voronoi" if args.config == 5 else "octree") + ">: all launches of one step, overlapped on the slot groups' streams "
-                                   "(denominator: segment_ms)",
-                         "kernel_ms": mean_ms, "walk_kernel_ms_sum": walk_ms_sum,
-                         "transition_kernel_ms": sum(t["transition_ms"] for t in timings) / len(timings),
-                         "segment_ms": mean_ms,
-                         "generations": sum(t["generations"] for t in timings) / len(timings),
-                         "cell_visits_per_packet": V / P, "detector_updates_per_packet": U / P,
-                         "rewalk_visits_per_packet": counters["rewalk_visits"] / launches / P,
-                         "algorithmic_bytes_per_packet": bytes_per_launch / P, "algorithmic_bytes_per_visit": bytes_per_visit},
+            "roofline": roof,
         }
+        if secondary is not None:
+            sroof = roofline_of(secondary)
+            out["secondary"] = {"workload": "the same octree with a UniformBoxGeometry source of +-10 x +-10 x +-1 kpc (north_star's second "
+                                            "source), 3 steps after 1 warm-up, same packet count per step",
+                                "value": total_per_step * 3 / secondary["elapsed"], "unit": "photon packets/s",
+                                "ms_per_step": 1e3 * secondary["elapsed"] / 3,
+                                "roofline": {k: sroof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "segment_ms",
+                                                                   "cell_visits_per_packet", "detector_updates_per_packet",
+                                                                   "algorithmic_bytes_per_packet")}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.ski if args.source == "sersic" else ski_path, os.environ.get("SKH_INPUT_PATH"))
         else:

@@ -42,9 +42,10 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 4
+#define PMC_ABI_VERSION 5
 
-enum { PMC_OK = 0, PMC_ERR_INVALID = -1, PMC_ERR_UNSUPPORTED = -2, PMC_ERR_DEVICE = -3, PMC_ERR_NOMEM = -4 };
+enum { PMC_OK = 0, PMC_ERR_INVALID = -1, PMC_ERR_UNSUPPORTED = -2, PMC_ERR_DEVICE = -3, PMC_ERR_NOMEM = -4,
+       PMC_ERR_OVERFLOW = -5 /* a history contributed to more distinct pixels than the statistics list holds */ };
 
 /* ---------------------------------------------------------------- spatial grid ---- */
 
@@ -274,7 +275,10 @@ int pmc_clear_frames(pmc_ctx* ctx);
    thread drives the generations of the two device kernels and returns when the segment is complete (the frames
    stay on the device; pmc_download copies them).  The RNG stream of a history depends only on (seed, history
    index), so any partition of [0,Npp) over calls and devices gives the same result up to the summation order of
-   the floating-point atomics. */
+   the floating-point atomics.
+   FluxRecorder::recordContributions keeps every contribution of a history (FluxRecorder.cpp:962-1014); the engine's
+   per-history list holds PMC_STAT_CAP = 48 DISTINCT pixels per instrument.  If a history of the segment exceeded that,
+   the statistics arrays are wrong and the call returns PMC_ERR_OVERFLOW (the flux arrays are unaffected). */
 int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed);
 int pmc_sync(pmc_ctx* ctx);
 int pmc_download(pmc_ctx* ctx, double* host_frames, int64_t num_doubles);
@@ -306,6 +310,32 @@ int pmc_set_num_slots(pmc_ctx* ctx, int64_t num_slots);
    its transition + launch kernel launches, and the number of generations (walk, transition, launch kernel triples,
    counted over all slot groups) */
 int pmc_last_timing(pmc_ctx* ctx, float* total_ms, float* walk_ms, float* transition_ms, int32_t* generations);
+
+/* ---------------------------------------------------------------- several GPUs: one segment over RCCL ---- */
+
+/* The histories of a segment shard by index over the devices: rank g of G runs [floor(g N / G), floor((g+1) N / G)) --
+   the static counterpart of the reference's chunk server (SKIRT/core/MultiHybridParallel.cpp:26-104); the random stream
+   of a history depends only on (seed, history index), so the partition does not change the result. */
+void pmc_history_range(uint64_t num_packets, int32_t rank, int32_t num_ranks, uint64_t* first, uint64_t* count);
+
+/* RCCL communicator handles cross this ABI as opaque pointers (ncclComm_t of <rccl/rccl.h>).
+   pmc_comm_init_all: one communicator per listed device for ONE process that drives them all (ncclCommInitAll);
+   pmc_comm_init_rank: the communicator of this process in a job of one process per device (ncclCommInitRank; unique_id
+   = the 128 bytes of an ncclUniqueId that rank 0 obtained with pmc_comm_unique_id and handed to the other processes). */
+#define PMC_COMM_ID_BYTES 128
+int  pmc_comm_init_all(int32_t num_devices, const int32_t* devices, void** comms);
+int  pmc_comm_unique_id(void* unique_id);
+int  pmc_comm_init_rank(int32_t device, int32_t num_ranks, int32_t rank, const void* unique_id, void** comm);
+void pmc_comm_destroy(void* comm);
+
+/* End of a segment: the detector arrays of all ranks are summed onto `root` with ONE ncclReduce (f64, sum) on the
+   context's stream, in place -- FluxRecorder::flush -> ProcessManager::sumToRoot (SKIRT/core/FluxRecorder.cpp:487-493,
+   SKIRT/mpi/ProcessManager.cpp:223-255).  The other ranks' arrays are cleared afterwards (they start the next segment
+   from zero, as the reference's do after the sum).  Every rank of the communicator must call it. */
+int pmc_reduce_frames(pmc_ctx* ctx, void* comm, int32_t root);
+/* The radiation field table of all ranks summed onto ALL ranks (ncclAllReduce): MediumSystem::communicateRadiationField
+   -> ProcessManager::sumToAll (SKIRT/core/MediumSystem.cpp:1304-1313). */
+int pmc_allreduce_radiation_field(pmc_ctx* ctx, void* comm);
 
 /* ---------------------------------------------------------------- setup: density of a smoothed-particle medium ---- */
 

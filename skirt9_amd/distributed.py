@@ -1,5 +1,12 @@
-"""Multi-GPU sharding of a primary-emission segment: one process per GPU, torch.distributed (backend "nccl" = RCCL on
-ROCm; "gloo" in the CPU tests).
+"""Multi-GPU sharding of a primary-emission segment for Python callers that hold the detector arrays in torch tensors:
+one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).  The product path
+without torch is in the engine library itself: ``pmc_reduce_frames`` / ``pmc_allreduce_radiation_field`` over an RCCL
+communicator (include/pmc.h; ``skirt_mi355x -g 0,1,...`` drives one host thread per device through them).
+
+Ordering contract: the engine runs on its own HIP streams.  ``Engine.run_primary`` returns only when the segment is
+complete on the device, so a collective issued on torch's stream afterwards sees the finished arrays; before the NEXT
+``run_primary`` the caller must make torch's work on the bound tensors visible (``torch.cuda.synchronize()`` or an
+event), as ``bench.py`` does.
 
 Photon histories are independent (performLifeCycle touches only thread-local state and atomically-added detector
 arrays), so a segment of Npp histories is split statically by index -- rank g of G takes
@@ -12,10 +19,10 @@ too because a history lives on exactly one rank.
 
 
 def history_range(num_packets, rank, world):
-    """[first, first+count) of this rank for a segment of num_packets histories"""
-    first = (rank * num_packets) // world
-    last = ((rank + 1) * num_packets) // world
-    return first, last - first
+    """[first, first+count) of this rank for a segment of num_packets histories: pmc_history_range of the engine library
+    (include/pmc.h), the implementation the CLI driver ``skirt_mi355x -g 0,1,...`` uses as well"""
+    from .engine import history_range as _range
+    return _range(num_packets, rank, world)
 
 
 def reduce_frames(frames, dst=0):

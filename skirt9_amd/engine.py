@@ -20,7 +20,8 @@ SYMBOLS = ["pmc_abi_version", "pmc_last_error", "pmc_frame_layout_of", "pmc_crea
            "pmc_last_kernel_ms", "pmc_counters", "pmc_reset_counters", "pmc_trace_ray", "pmc_set_launch",
            "pmc_set_num_slots", "pmc_last_timing", "pmc_radiation_field_size", "pmc_radiation_field_device",
            "pmc_download_radiation_field", "pmc_clear_radiation_field", "pmc_bind_radiation_field", "pmc_sampler_create",
-           "pmc_sampler_density", "pmc_sampler_destroy"]
+           "pmc_sampler_density", "pmc_sampler_destroy", "pmc_history_range", "pmc_comm_init_all", "pmc_comm_unique_id",
+           "pmc_comm_init_rank", "pmc_comm_destroy", "pmc_reduce_frames", "pmc_allreduce_radiation_field"]
 
 _lib = None
 
@@ -63,6 +64,15 @@ def lib():
         L.pmc_download_radiation_field.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.pmc_clear_radiation_field.argtypes = [C.c_void_p]
         L.pmc_bind_radiation_field.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.pmc_history_range.restype = None
+        L.pmc_history_range.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.pmc_comm_init_all.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]
+        L.pmc_comm_unique_id.argtypes = [C.c_void_p]
+        L.pmc_comm_init_rank.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.pmc_comm_destroy.restype = None
+        L.pmc_comm_destroy.argtypes = [C.c_void_p]
+        L.pmc_reduce_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.pmc_allreduce_radiation_field.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -70,6 +80,48 @@ def lib():
 def _check(rc):
     if rc != 0:
         raise RuntimeError(f"pmc error {rc}: {lib().pmc_last_error().decode()}")
+
+
+def history_range(num_packets, rank, num_ranks):
+    """[first, first + count) of rank `rank` of `num_ranks` for a segment of num_packets histories (pmc_history_range:
+    the one implementation the CLI driver, the bench and the tests share; pure host code)"""
+    first, count = C.c_uint64(0), C.c_uint64(0)
+    lib().pmc_history_range(int(num_packets), int(rank), int(num_ranks), C.byref(first), C.byref(count))
+    return int(first.value), int(count.value)
+
+
+class Communicator:
+    """RCCL communicator(s) behind the C ABI: ``Communicator.all(devices)`` for one process that drives several
+    devices (one handle per device), ``Communicator.rank(device, num_ranks, rank, unique_id)`` for one process per
+    device (``Communicator.unique_id()`` on rank 0, handed to the others by the launcher)."""
+
+    def __init__(self, handles):
+        self.handles = handles
+
+    @classmethod
+    def all(cls, devices):
+        n = len(devices)
+        dev = (C.c_int32 * n)(*devices)
+        out = (C.c_void_p * n)()
+        _check(lib().pmc_comm_init_all(n, dev, out))
+        return cls([C.c_void_p(h) for h in out])
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(lib().pmc_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def rank(cls, device, num_ranks, rank, unique_id):
+        out = C.c_void_p()
+        _check(lib().pmc_comm_init_rank(device, num_ranks, rank, C.c_char_p(unique_id), C.byref(out)))
+        return cls([out])
+
+    def close(self):
+        for h in self.handles:
+            lib().pmc_comm_destroy(h)
+        self.handles = []
 
 
 class Engine:
@@ -131,6 +183,15 @@ class Engine:
         _check(lib().pmc_last_timing(self._h, C.byref(t), C.byref(w), C.byref(x), C.byref(g)))
         return {"total_ms": float(t.value), "walk_ms": float(w.value), "transition_ms": float(x.value),
                 "generations": int(g.value)}
+
+    def reduce_frames(self, comm_handle, root=0):
+        """end of a segment on several devices: ONE ncclReduce (f64, sum) of the detector arrays onto `root`
+        (ProcessManager::sumToRoot behind FluxRecorder::flush); the other ranks' arrays are cleared"""
+        _check(lib().pmc_reduce_frames(self._h, comm_handle, root))
+
+    def allreduce_radiation_field(self, comm_handle):
+        """ncclAllReduce of the radiation field table (MediumSystem::communicateRadiationField)"""
+        _check(lib().pmc_allreduce_radiation_field(self._h, comm_handle))
 
     def download(self):
         out = np.empty(self.frame_size, dtype=np.float64)

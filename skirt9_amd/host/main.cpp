@@ -1,6 +1,11 @@
 // main.cpp -- command line driver: runs an unchanged SKIRT ski file with the primary-emission loop on the MI355X.
 //
-//   skirt_mi355x [-o outdir] [-g device] [-n packets] [-s] file.ski     (-s: particle-medium densities sampled on the GPU)
+//   skirt_mi355x [-o outdir] [-g device[,device...]] [-n packets] [-s] [--rccl] file.ski
+//        -g 0,1,2,3   the devices that share the segment: one host thread per device, the histories split statically by
+//                     index (pmc_history_range), ONE RCCL reduce of the detector arrays onto the first device at the end
+//                     of the segment (ProcessManager::sumToRoot, FluxRecorder.cpp:487-493), which writes the output
+//        -s           particle-medium densities sampled on the GPU during setup
+//        --rccl       run the collective also with a single device (a one-rank communicator: checks the call path)
 //
 // Counterpart of SKIRT/main (SkirtCommandLineHandler.cpp:295-372 doSimulation): construct the simulation from the
 // ski file, set it up, run the primary emission segment (here: on the GPU through the C ABI of include/pmc.h),
@@ -13,14 +18,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 int main(int argc, char** argv)
 {
     std::string outdir = ".", ski;
-    int device = 0;
+    std::vector<int32_t> devices;
     unsigned long long packets = 0;
-    bool deviceSetup = false;
+    bool deviceSetup = false, forceComm = false;
     for (int i = 1; i < argc; ++i)
     {
         if (!strcmp(argv[i], "-s"))
@@ -30,8 +36,16 @@ int main(int argc, char** argv)
         }
         else if (!strcmp(argv[i], "-o") && i + 1 < argc)
             outdir = argv[++i];
+        else if (!strcmp(argv[i], "--rccl"))
+            forceComm = true;
         else if (!strcmp(argv[i], "-g") && i + 1 < argc)
-            device = atoi(argv[++i]);
+        {
+            for (const char* p = argv[++i]; *p;)
+            {
+                devices.push_back((int32_t)strtol(p, const_cast<char**>(&p), 10));
+                if (*p == ',') ++p;
+            }
+        }
         else if (!strcmp(argv[i], "-n") && i + 1 < argc)
             packets = strtoull(argv[++i], nullptr, 10);
         else
@@ -39,9 +53,12 @@ int main(int argc, char** argv)
     }
     if (ski.empty())
     {
-        fprintf(stderr, "usage: skirt_mi355x [-o outdir] [-g device] [-n packets] [-s] file.ski\n");
+        fprintf(stderr, "usage: skirt_mi355x [-o outdir] [-g device[,device...]] [-n packets] [-s] [--rccl] file.ski\n");
         return 2;
     }
+    if (devices.empty()) devices.push_back(0);
+    const int device = devices[0];
+    const int G = (int)devices.size();
     using clock = std::chrono::steady_clock;
     auto seconds = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 
@@ -72,49 +89,87 @@ int main(int argc, char** argv)
     auto t1 = clock::now();
     printf("%sFinished setup in %.1f s.\n", summary, seconds(t0, t1));
 
-    pmc_ctx* ctx = nullptr;
-    if (pmc_create(skh_scene(sim), device, &ctx) != PMC_OK)
-    {
-        fprintf(stderr, "Fatal error: %s\n", pmc_last_error());
-        return 1;
-    }
+    // ---- the segment: one host thread and one engine context per device, every device a replica of the scene and a
+    //      static range of the history indices; one RCCL reduce of the detector arrays onto the first device
     const unsigned long long n = skh_num_packets(sim);
-    printf("Launching %g primary emission photon packets\n", (double)n);
-    auto t2 = clock::now();
-    std::vector<double> frames(skh_frame_size(sim));
-    if (pmc_run_primary(ctx, 0, n, (uint64_t)skh_seed(sim)) != PMC_OK || pmc_download(ctx, frames.data(), (int64_t)frames.size()) != PMC_OK)
+    const bool useComm = G > 1 || forceComm;
+    std::vector<void*> comms(G, nullptr);
+    if (useComm && pmc_comm_init_all(G, devices.data(), comms.data()) != PMC_OK)
     {
         fprintf(stderr, "Fatal error: %s\n", pmc_last_error());
         return 1;
     }
+    printf("Launching %g primary emission photon packets on %d device%s%s\n", (double)n, G, G > 1 ? "s" : "",
+           useComm ? " (detector arrays summed over RCCL)" : "");
+    auto t2 = clock::now();
+    std::vector<pmc_ctx*> ctxs(G, nullptr);
+    std::vector<std::string> errors(G);
+    std::vector<pmc_counter_values> counts(G);
+    std::vector<double> frames(skh_frame_size(sim));
+    std::vector<double> rf(skh_radiation_field_size(sim));
+    auto work = [&](int g) {
+        auto failed = [&]() { errors[g] = pmc_last_error(); };
+        if (pmc_create(skh_scene(sim), devices[g], &ctxs[g]) != PMC_OK) return failed();
+        uint64_t first = 0, count = 0;
+        pmc_history_range(n, g, G, &first, &count);
+        if (pmc_run_primary(ctxs[g], first, count, (uint64_t)skh_seed(sim)) != PMC_OK) return failed();
+        pmc_counters(ctxs[g], &counts[g]);
+        if (useComm && pmc_reduce_frames(ctxs[g], comms[g], 0) != PMC_OK) return failed();
+        if (useComm && !rf.empty() && pmc_allreduce_radiation_field(ctxs[g], comms[g]) != PMC_OK) return failed();
+        if (g == 0)
+        {
+            if (pmc_download(ctxs[g], frames.data(), (int64_t)frames.size()) != PMC_OK) return failed();
+            if (!rf.empty() && pmc_download_radiation_field(ctxs[g], rf.data(), (int64_t)rf.size()) != PMC_OK) return failed();
+        }
+    };
+    {
+        std::vector<std::thread> threads;
+        for (int g = 1; g < G; ++g) threads.emplace_back(work, g);
+        work(0);
+        for (auto& t : threads) t.join();
+    }
+    for (int g = 0; g < G; ++g)
+        if (!errors[g].empty())
+        {
+            fprintf(stderr, "Fatal error (device %d): %s\n", devices[g], errors[g].c_str());
+            return 1;
+        }
     auto t3 = clock::now();
-    pmc_counter_values c;
-    pmc_counters(ctx, &c);
+    pmc_counter_values c{};
+    for (int g = 0; g < G; ++g)
+    {
+        c.cell_visits += counts[g].cell_visits;
+        c.detector_updates += counts[g].detector_updates;
+        c.stat_overflows += counts[g].stat_overflows;
+    }
     printf("Finished primary emission in %.3f s (%.3g packets/s; %.1f cell visits and %.1f detector updates per packet).\n",
            seconds(t2, t3), n / seconds(t2, t3), (double)c.cell_visits / n, (double)c.detector_updates / n);
+    if (c.stat_overflows)
+    {
+        // FluxRecorder::recordContributions keeps every contribution of a history (FluxRecorder.cpp:962-1014); the engine's
+        // per-history list is bounded, and statistics computed from a truncated list would be wrong: no output
+        fprintf(stderr, "Fatal error: %llu photon histories contributed to more distinct pixels of an instrument than the engine's "
+                        "statistics list holds; rerun with recordStatistics=\"false\"\n", (unsigned long long)c.stat_overflows);
+        return 1;
+    }
     if (skh_write(sim, frames.data(), outdir.c_str()) != 0)
     {
         fprintf(stderr, "Fatal error: %s\n", skh_last_error());
         return 1;
     }
-    // the radiation field, if the ski file stores it: downloaded after the segment and written by the configured
-    // RadiationFieldProbe (the reference sums it over processes first, MediumSystem.cpp:1304-1313; one GPU here)
-    if (const int64_t rfSize = skh_radiation_field_size(sim))
+    // the radiation field, if the ski file stores it: summed over the devices (MediumSystem.cpp:1304-1313) and written by
+    // the configured RadiationFieldProbe
+    if (!rf.empty() && skh_write_radiation_field(sim, rf.data(), outdir.c_str()) != 0)
     {
-        std::vector<double> rf(rfSize);
-        if (pmc_download_radiation_field(ctx, rf.data(), rfSize) != PMC_OK)
-        {
-            fprintf(stderr, "Fatal error: %s\n", pmc_last_error());
-            return 1;
-        }
-        if (skh_write_radiation_field(sim, rf.data(), outdir.c_str()) != 0)
-        {
-            fprintf(stderr, "Fatal error: %s\n", skh_last_error());
-            return 1;
-        }
+        fprintf(stderr, "Fatal error: %s\n", skh_last_error());
+        return 1;
     }
     printf("Finished final output in %.1f s.\n", seconds(t3, clock::now()));
-    pmc_destroy(ctx);
+    for (int g = 0; g < G; ++g)
+    {
+        pmc_destroy(ctxs[g]);
+        pmc_comm_destroy(comms[g]);
+    }
     skh_free(sim);
     return 0;
 }

@@ -27,7 +27,17 @@ def test_every_declared_symbol_is_exported(libpmc):
     assert sorted(engine.SYMBOLS) == declared
     for name in declared:
         assert hasattr(libpmc, name), name
-    assert libpmc.pmc_abi_version() == 4
+    assert libpmc.pmc_abi_version() == 5
+
+
+def test_history_range_is_the_library_function(libpmc):
+    """skirt9_amd.distributed.history_range, the CLI driver and the bench share pmc_history_range (pure host code)"""
+    from skirt9_amd.distributed import history_range
+    for n, world in ((10 ** 9, 8), (7, 3), (0, 4), (2 ** 63 + 12345, 8)):
+        cuts = [history_range(n, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and sum(c for _, c in cuts) == n
+        for r in range(world):
+            assert cuts[r][0] == (r * n) // world and cuts[r][1] == ((r + 1) * n) // world - (r * n) // world
 
 
 def test_host_library_exports(libpmc):
