@@ -22,6 +22,7 @@ python3 - <<'PY'
 import csv, glob, collections, os
 out = os.environ.get("OUTDIR", os.getcwd() + "/gpurun_out/pmc")
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
+passes = collections.defaultdict(lambda: collections.defaultdict(set))
 calls = collections.defaultdict(set)
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
@@ -30,7 +31,11 @@ for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
         if not m: continue
         k = m.group(1)
         tot[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        passes[k][row["Counter_Name"]].add(f)
         calls[k].add((f, row["Dispatch_Id"]))
+for k in tot:
+    for c in tot[k]:
+        tot[k][c] /= len(passes[k][c])  # a counter listed in several passes: the mean over them
 with open(out + "/summary.txt", "w") as fh:
     for k in sorted(tot):
         fh.write(f"== {k}\n")
