@@ -422,10 +422,10 @@ namespace
         int32_t** ints[] = {&A.dustIndex, &A.mode, &A.nscatt, &A.pscatt, &A.cellhint, &A.mint};
         for (int32_t** d : ints)
             if ((rc = ctx->allocate<int32_t>(n, d, true, &own))) return rc;
-        if ((rc = ctx->allocate<double>(size_t(n) * PMC_MAX_INSTRUMENTS, &A.ppW, false, &own))) return rc;
-        if ((rc = ctx->allocate<double>(size_t(n) * PMC_MAX_INSTRUMENTS, &A.ptau, false, &own))) return rc;
-        if ((rc = ctx->allocate<int32_t>(size_t(n) * PMC_MAX_INSTRUMENTS, &A.ell, true, &own))) return rc;
-        if ((rc = ctx->allocate<int32_t>(size_t(n) * PMC_MAX_INSTRUMENTS, &A.nstat, true, &own))) return rc;
+        if ((rc = ctx->allocate<double>(size_t(n) * size_t(ctx->dev.num_instruments), &A.ppW, false, &own))) return rc;
+        if ((rc = ctx->allocate<double>(size_t(n) * size_t(ctx->dev.num_instruments), &A.ptau, false, &own))) return rc;
+        if ((rc = ctx->allocate<int32_t>(size_t(n) * size_t(ctx->dev.num_instruments), &A.ell, true, &own))) return rc;
+        if ((rc = ctx->allocate<int32_t>(size_t(n) * size_t(ctx->dev.num_instruments), &A.nstat, true, &own))) return rc;
         if (ctx->dev.rf_store && (rc = ctx->allocate<int32_t>(n, &A.rfell, true, &own))) return rc;
         if (ctx->dev.any_stats)
         {
@@ -744,7 +744,8 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         d.num_levels = I.num_scattering_levels;
         d.record_stats = I.record_statistics;
         d.aperture_r2 = I.aperture_radius2;
-        if (I.redshift != 0.) return bail(fail(PMC_ERR_UNSUPPORTED, "instrument redshift is not supported"));
+        if (!(I.redshift >= 0.)) return bail(fail(PMC_ERR_INVALID, "negative instrument redshift"));
+        d.zp1 = 1. + I.redshift;
         d.num_lambda = I.num_lambda;
         d.num_border = I.num_border;
         if ((rc = ctx->upload(I.border, I.num_border, &d.border))) return bail(rc);

@@ -18,7 +18,8 @@
 #include "../../include/pmc.h"
 #include <stdint.h>
 
-#define PMC_MAX_INSTRUMENTS 4
+#define PMC_MAX_INSTRUMENTS 8   // (the observers with a peel-off packet of a cycle are flagged in eight bits of the slot's mode word;
+                                // the per-instrument slot arrays are sized by the scene's own instrument count)
 #define PMC_MAX_CONTEXTS 8  // scene slots in constant memory (live contexts per process and device)
 #define PMC_MAX_LEVEL 12
 #define PMC_STAT_CAP 48     // per-history list capacity per instrument: DISTINCT pixels a history contributes to (FluxRecorder
@@ -78,6 +79,7 @@ struct DevInstrument
     int32_t same_observer;
     int32_t include_sed, include_ifu, record_components, num_levels, record_stats;
     double aperture_r2;  // SEDInstrument aperture radius squared (0: none)
+    double zp1;          // 1 + redshift of the observer frame: the wavelength bins are looked up at lambda (1 + z) (FluxRecorder.cpp:309-310)
     int32_t num_lambda, num_border;
     const double* border;   // device
     const int32_t* ellv;    // device
@@ -97,7 +99,7 @@ struct SlotArrays
     double* lambda;                         // wavelength
     double* W;                              // weight (luminosity = W / lambda)
     double* Lthreshold;
-    double* ppW;                            // [PMC_MAX_INSTRUMENTS][num_slots] weight of the cycle's peel-off packet towards
+    double* ppW;                            // [num_instruments][num_slots] weight of the cycle's peel-off packet towards
                                             // the observer whose instrument group starts at that instrument
     double* taupath;                        // optical depth of the whole path (pass 1), kept for the escape weight
     double* tausample;                      // interaction optical depth sampled between the passes (path-length-bias weight)
@@ -109,11 +111,11 @@ struct SlotArrays
     int32_t* nscatt;
     int32_t* pscatt;                        // numScatt of the cycle's peel-off packets (0: emission)
     int32_t* cellhint;                      // octree leaf that contains the position, or -1
-    int32_t* ell;                           // [PMC_MAX_INSTRUMENTS][num_slots] wavelength bin per instrument
-    int32_t* nstat;                         // [PMC_MAX_INSTRUMENTS][num_slots] length of the contribution list
+    int32_t* ell;                           // [num_instruments][num_slots] wavelength bin per instrument
+    int32_t* nstat;                         // [num_instruments][num_slots] length of the contribution list
     int32_t* rfell;                         // wavelength bin in the radiation field grid, -1 outside (only if rf_store)
     // walk results
-    double* ptau;                           // [PMC_MAX_INSTRUMENTS][num_slots] optical depth towards that observer (inf: the
+    double* ptau;                           // [num_instruments][num_slots] optical depth towards that observer (inf: the
                                             // contribution is zero)
     double* sint;                           // propagation walk: interaction distance
     double* nint;                           //         density of the interaction cell

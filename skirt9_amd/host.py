@@ -104,6 +104,7 @@ class Simulation:
 
     def __init__(self, ski_path, num_packets=None, tree_topology=None):
         L = lib()
+        self.path = str(ski_path)
         self._h = L.skh_load(os.fsencode(ski_path))
         if not self._h:
             raise RuntimeError(L.skh_last_error().decode())

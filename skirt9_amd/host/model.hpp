@@ -535,6 +535,8 @@ namespace skh
         std::string type;  // FrameInstrument | FullInstrument
         std::string name;
         double distance{0}, inclination{0}, azimuth{0}, roll{0};
+        // observer frame (DistantInstrument.cpp:24-36): an instrument at distance zero in a model at redshift z > 0
+        double redshift{0}, luminosityDistance{0}, angularDiameterDistance{0};
         double fieldOfViewX{0}, fieldOfViewY{0}, centerX{0}, centerY{0};
         int numPixelsX{250}, numPixelsY{250};
         double radius{0};  // SEDInstrument: aperture radius (0: none)

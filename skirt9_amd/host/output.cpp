@@ -323,7 +323,8 @@ namespace skh
             const bool totalOnly = !p.record_components;
             const int maxContributionPower = 4;
 
-            double luminosityDistance = ins.distance, angularDiameterDistance = ins.distance;  // setRestFrameDistance
+            // setRestFrameDistance / setObserverFrameRedshift (FluxRecorder.cpp:112-128)
+            double luminosityDistance = ins.luminosityDistance, angularDiameterDistance = ins.angularDiameterDistance;
             double pixelSizeX = ins.fieldOfViewX / ins.numPixelsX, pixelSizeY = ins.fieldOfViewY / ins.numPixelsY;
             double fourpid2 = 4. * M_PI * (luminosityDistance * luminosityDistance);
             double omega = 4. * atan(0.5 * pixelSizeX / angularDiameterDistance) * atan(0.5 * pixelSizeY / angularDiameterDistance);
@@ -332,7 +333,13 @@ namespace skh
                 std::string h = "# " + name + " at ";
                 h += "inclination " + smartString(_units.out("posangle", ins.inclination)) + " " + _units.unit("posangle");
                 h += ", azimuth " + smartString(_units.out("posangle", ins.azimuth)) + " " + _units.unit("posangle");
-                h += ", distance " + smartString(_units.out("distance", luminosityDistance)) + " " + _units.unit("distance");
+                if (ins.redshift)
+                {
+                    h += ", redshift " + smartString(ins.redshift);
+                    h += ", luminosity distance " + smartString(_units.out("distance", luminosityDistance)) + " " + _units.unit("distance");
+                }
+                else
+                    h += ", distance " + smartString(_units.out("distance", luminosityDistance)) + " " + _units.unit("distance");
                 return h;
             };
 
@@ -435,7 +442,7 @@ namespace skh
                 info.inclination = ins.inclination * (180. / M_PI);
                 info.azimuth = ins.azimuth * (180. / M_PI);
                 info.roll = ins.roll * (180. / M_PI);
-                info.redshift = 0.;
+                info.redshift = ins.redshift;
                 info.luminosityDistance = _units.out("distance", luminosityDistance);
                 info.angularDiameterDistance = _units.out("distance", angularDiameterDistance);
                 info.distanceUnits = _units.unit("distance");

@@ -205,7 +205,32 @@ namespace skh
             _seed = rd.integer(*r, "seed", 0);
         }
         if (const XmlElement* c = sim.item("cosmology"))
-            if (c->name != "LocalUniverseCosmology") unsupported("cosmology " + c->name);
+        {
+            if (c->name == "FlatUniverseCosmology")
+            {
+                // the model sits at redshift z in a flat universe (FlatUniverseCosmology.cpp:18-53): comoving distance
+                // c/H0 * integral of dz' / sqrt(Om (1+z')^3 + 1 - Om) by the midpoint rule on max(2000, 10000 z) intervals
+                const double z = rd.number(*c, "redshift", "1");
+                const double h = rd.number(*c, "reducedHubbleConstant", "0.675");
+                const double Om = rd.number(*c, "matterDensityFraction", "0.310");
+                if (!(z > 0.)) unsupported("FlatUniverseCosmology with redshift zero");
+                const double front = 10. * constants::pc * constants::c / h;
+                const int n = std::max(2000, static_cast<int>(z * 10000));
+                const double dz = z / n;
+                double sum = 0.;
+                for (int i = 0; i != n; ++i)
+                {
+                    const double zp1 = (i + 0.5) * dz + 1.;
+                    sum += 1. / sqrt(Om * zp1 * zp1 * zp1 + (1. - Om));
+                }
+                const double comoving = front * z * sum / n;
+                _modelRedshift = z;
+                _cosmoAngularDiameterDistance = comoving / (1. + z);
+                _cosmoLuminosityDistance = comoving * (1. + z);
+            }
+            else if (c->name != "LocalUniverseCosmology")
+                unsupported("cosmology " + c->name);
+        }
 
         // ---- source system (SourceSystem.hpp properties)
         const XmlElement* ss = sim.item("sourceSystem");
@@ -554,7 +579,6 @@ namespace skh
             // an aperture radius around the line of sight
             if (ie->name == "SEDInstrument") ins.radius = rd.quantity(*ie, "radius", "length", "0");
             ins.name = ie->attr("instrumentName");
-            ins.distance = rd.quantity(*ie, "distance", "distance");
             ins.inclination = rd.quantity(*ie, "inclination", "posangle", "0 deg");
             ins.azimuth = rd.quantity(*ie, "azimuth", "posangle", "0 deg");
             ins.roll = rd.quantity(*ie, "roll", "posangle", "0 deg");
@@ -572,7 +596,19 @@ namespace skh
             ins.recordPolarization = rd.boolean(*ie, "recordPolarization", false);
             ins.recordStatistics = rd.boolean(*ie, "recordStatistics", false);
             if (ins.recordPolarization) unsupported("recordPolarization");
-            if (ins.distance <= 0.) unsupported("an instrument at zero distance (model redshift)");
+            // DistantInstrument.cpp:24-36: a distance puts the instrument in the model's rest frame; distance zero means the
+            // observer frame of a model at redshift z > 0 (distances from the cosmology, wavelengths shifted by 1 + z)
+            ins.distance = rd.quantity(*ie, "distance", "distance", "0");
+            if (ins.distance > 0.)
+                ins.luminosityDistance = ins.angularDiameterDistance = ins.distance;
+            else if (_modelRedshift > 0.)
+            {
+                ins.redshift = _modelRedshift;
+                ins.luminosityDistance = _cosmoLuminosityDistance;
+                ins.angularDiameterDistance = _cosmoAngularDiameterDistance;
+            }
+            else
+                throw std::runtime_error("Instrument distance and model redshift are both zero");
             if (const XmlElement* wg = ie->item("wavelengthGrid")) ins.ownGrid = makeWavelengthGrid(*wg, rd);
             _instruments.push_back(std::move(ins));
         }
@@ -1008,7 +1044,7 @@ namespace skh
             p.record_components = ins.recordComponents;  // a medium is always present on this path
             p.num_scattering_levels = ins.recordComponents ? ins.numScatteringLevels : 0;
             p.record_statistics = ins.recordStatistics;
-            p.redshift = 0.;
+            p.redshift = ins.redshift;
             p.num_lambda = ins.grid->numBins();
             p.num_border = static_cast<int32_t>(ins.grid->borderv.size());
             p.border = ins.grid->borderv.data();

@@ -75,6 +75,8 @@ namespace skh
         ParticleSamplerApi _samplerApi;
         OutputUnits _units;
         int _seed{0};
+        // cosmology (Configuration.cpp:52-55): redshift of the model and the two distances of an observer at that redshift
+        double _modelRedshift{0}, _cosmoAngularDiameterDistance{0}, _cosmoLuminosityDistance{0};
         Random _random;
         bool _oligo{false};
         uint64_t _numPackets{0};

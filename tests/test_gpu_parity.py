@@ -75,10 +75,14 @@ def _compare_frames(sim, gpu, ref, n):
         a = gpu[lay.wsed_offset:lay.wsed_offset + 5 * lay.num_lambda]
         b = ref[lay.wsed_offset:lay.wsed_offset + 5 * lay.num_lambda]
         assert np.allclose(a, b, rtol=1e-9, atol=0)
-        assert a[:lay.num_lambda].sum() == n  # sum of w^0 over the wavelength bins = histories that reached the SED
+        # sum of w^0 over the wavelength bins = histories that reached the SED: all of them, unless the instrument sits in the
+        # observer frame of a model at redshift z (cfg3z: packets whose lambda (1+z) falls outside the instrument's grid)
+        assert a[:lay.num_lambda].sum() == b[:lay.num_lambda].sum() and a[:lay.num_lambda].sum() <= n
+        if "cfg3z" not in sim.path:
+            assert a[:lay.num_lambda].sum() == n
 
 
-@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000)])
+@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000)])
 def test_photon_loop_matches_oracle(name, n):
     sim = Simulation(ski(name), num_packets=n).setup()
     eng = _engine(sim)
