@@ -26,6 +26,7 @@ extern "C" hipError_t pmcUploadScene(int slot, const DevScene* scene, hipStream_
 extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds);
 extern "C" int pmcWalkBlocksPerCU(int gridKind, int kind, int wide, int block, size_t ldsBytes);
 extern "C" int pmcPeelBlock(void);
+extern "C" int pmcPropBlock(void);
 extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int taskBase, int numTaskRecords, int taskCounter, uint64_t seed, int grid,
                                     int block, size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, int cursor, int obs, int grid, size_t ldsBytes,
@@ -80,7 +81,7 @@ struct pmc_ctx
     bool sceneDirty{true};
     hipStream_t stream{nullptr};
     // slot groups: the generations of group g are enqueued on groupStream[g] (group 0 uses `stream`)
-    int numGroups{2};
+    int numGroups{3};
     hipStream_t groupStream[PMC_MAX_GROUPS]{};
     // octree: the peel-off kernels of a generation run on a side stream of the group, next to its propagation kernel
     hipStream_t peelStream[PMC_MAX_GROUPS]{};
@@ -802,10 +803,15 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     {
         // persistent walk kernels: as many workgroups as stay resident (the transition / launch kernels of the other
         // slot group get the CUs between generations)
-        int perCU = pmcWalkBlocksPerCU(D.grid_kind, D.grid_kind == PMC_GRID_OCTREE ? 2 : 0, ctx->wide, ctx->block, ctx->walkLds);
+        int perCU = pmcWalkBlocksPerCU(D.grid_kind, D.grid_kind == PMC_GRID_OCTREE ? 2 : 0, ctx->wide,
+                                       D.grid_kind == PMC_GRID_OCTREE ? pmcPropBlock() : ctx->block, ctx->walkLds);
         if (perCU < 1) perCU = 1;
+        // (octree propagation kernel: ONE workgroup of 256 lanes per CU.  The walk kernels are bound by the memory system's
+        // rate of random gathers, which falls when too many of them are in flight -- 32 MB table, 8 / 16 / 32 waves per CU:
+        // 1.9 / 0.94 / 0.83e11 records/s, profiles/microbench/gather_modes_mi355x.txt -- and the kernels of three slot groups
+        // overlap; 1 / 2 / 3 per CU: 697 / 720 / 756 ms per 1e8 packets)
         if (const char* env = getenv("PMC_WALK_BLOCKS_PER_CU")) perCU = std::min(perCU, std::max(1, atoi(env)));  // tuning aid
-        else if (D.grid_kind != PMC_GRID_OCTREE) perCU = std::min(perCU, 3);
+        else perCU = std::min(perCU, D.grid_kind == PMC_GRID_OCTREE ? 1 : 3);
         ctx->grid = ctx->numCU * perCU;
         if (D.grid_kind == PMC_GRID_OCTREE)
         {
@@ -893,6 +899,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     unsigned long long* ctr = D.counters;
     float walkMs = 0, transMs = 0, peelMs = 0;
     const bool serialWalks = getenv("PMC_SERIAL_WALKS") != nullptr;  // tuning aid: peel-off and propagation kernels one after the other
+    const bool genDump = getenv("PMC_GEN_DUMP") != nullptr;  // tuning aid: live slots and kernel times of every generation
     int generations = 0;
     // ---- slot groups: group g owns the slots [base[g], base[g] + size[g]) and the stream groupStream[g].  The
     // generations of different groups are independent (histories come from one shared cursor), so while the host
@@ -978,11 +985,12 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         {
             if (!active[g]) continue;
             HIP_TRY(hipStreamSynchronize(ctx->groupStream[g]));
-            float ms = 0;
+            float ms = 0, walkOfGen = 0;
             if (haveWalk[g])
             {
                 HIP_TRY(hipEventElapsedTime(&ms, ctx->evA[g], ctx->evB[g]));
                 walkMs += ms;
+                walkOfGen = ms;
                 if (serialWalks && D.grid_kind == PMC_GRID_OCTREE)
                 {
                     HIP_TRY(hipEventElapsedTime(&ms, ctx->evA[g], ctx->evJoin[g]));
@@ -998,6 +1006,9 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 continue;
             }
             ++generations;
+            if (genDump)
+                fprintf(stderr, "PMC_GEN %d group %d live %llu walk_ms %.3f transition_ms %.3f\n", generations, g, ctx->pinned[g],
+                        haveWalk[g] ? walkOfGen : 0.f, ms);
             int rc = enqueue(g, false);
             if (rc) return rc;
         }

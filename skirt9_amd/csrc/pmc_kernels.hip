@@ -70,6 +70,9 @@
     #define PMC_PEEL_MIN_WAVES 6  // waves per SIMD the peel-off kernel's register budget must allow (<= 80 VGPRs; it uses 75,
                                   // and must not spill: see treeSlowStep)
 #endif
+#ifndef PMC_PROP_BLOCK
+    #define PMC_PROP_BLOCK 256  // lanes per workgroup of the propagation kernel
+#endif
 #ifndef PMC_PROP_MIN_WAVES
     #define PMC_PROP_MIN_WAVES 3  // likewise for the propagation kernel (<= 168 VGPRs; it uses 135-143)
 #endif
@@ -253,6 +256,10 @@ extern "C" int pmcPeelBlock(void)
 {
     return PMC_PEEL_BLOCK;
 }
+extern "C" int pmcPropBlock(void)
+{
+    return PMC_PROP_BLOCK;
+}
 
 // walks of the task records [taskBase, taskBase + numTaskRecords) of one slot group on a Cartesian or Voronoi grid;
 // taskCounter = index of the group's (zeroed) cursor
@@ -281,7 +288,7 @@ extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBas
 {
     auto kernel = wide ? (storeRf ? walkPropKernel<true, true> : walkPropKernel<true, false>)
                        : (storeRf ? walkPropKernel<false, true> : walkPropKernel<false, false>);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, cursor, seed);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PROP_BLOCK), ldsBytes, stream, slot, slotBase, numSlots, cursor, seed);
     return hipGetLastError();
 }
 
