@@ -25,6 +25,7 @@
 extern "C" hipError_t pmcUploadScene(int slot, const DevScene* scene, hipStream_t stream);
 extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds);
 extern "C" int pmcWalkBlocksPerCU(int gridKind, int kind, int wide, int block, size_t ldsBytes);
+extern "C" hipError_t pmcLaunchStatMerge(int slot, int blocks, hipStream_t stream);
 extern "C" int pmcPeelBlock(void);
 extern "C" int pmcPropBlock(void);
 extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int taskBase, int numTaskRecords, int taskCounter, uint64_t seed, int grid,
@@ -723,6 +724,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     D.lds_sed_off = transDoubles;
     int sedDoubles = 0;
     D.any_stats = 0;
+    D.stat_acc_records = 0;
     for (int i = 0; i < scene->num_instruments; ++i)
     {
         const pmc_instrument& I = scene->instruments[i];
@@ -759,7 +761,11 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         d.sed_lds_offset = sedDoubles;
         if (d.include_sed) sedDoubles += (d.num_components + (d.record_stats ? 5 : 0)) * d.num_lambda;
         if (d.record_stats) D.any_stats = 1;
+        d.stat_acc_offset = D.stat_acc_records;
+        if (d.record_stats && d.include_ifu) D.stat_acc_records += d.npix * d.num_lambda;
     }
+    D.stat_acc = nullptr;
+    if (D.stat_acc_records && (rc = ctx->allocate<double>(size_t(D.stat_acc_records) * 8, &D.stat_acc, true))) return bail(rc);
     // ---- radiation field table
     const pmc_radiation_field& RF = scene->radiation_field;
     D.rf_store = RF.store ? 1 : 0;
@@ -781,8 +787,6 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     transDoubles += sedDoubles;
     D.lds_hot_off = transDoubles;
     transDoubles += 2 * 256;  // hot-bin table (pmc_transition.inc HOT_BINS keys + values)
-    D.lds_stat_off = transDoubles;
-    transDoubles += 6 * 128;  // hot-bin table of the statistics (pmc_transition.inc STAT_BINS keys + 5 values each)
     D.lds_sort_off = transDoubles;
     transDoubles += (64 + 2 * 1024 + 8) / 2;  // integer scratch: regrouping arrays and list-append counters
     D.lds_total_transition = transDoubles;
@@ -1015,6 +1019,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         return PMC_OK;
     };
     if (int rc = drive()) return abandon(rc);
+    // the segment's statistics: accumulator records -> wifu arrays (every group's stream has been waited for)
+    if (D.stat_acc_records) HIP_TRY(pmcLaunchStatMerge(ctx->slot, ctx->numCU * 8, st));
     HIP_TRY(hipEventRecord(ctx->evStop, st));
     HIP_TRY(hipEventSynchronize(ctx->evStop));
     HIP_TRY(hipEventElapsedTime(&ctx->totalMs, ctx->evStart, ctx->evStop));

@@ -87,6 +87,7 @@ struct DevInstrument
     int64_t sed_offset, ifu_offset, wsed_offset, wifu_offset, npix;
     int32_t num_components;
     int32_t sed_lds_offset;  // offset (doubles) of this instrument's privatised SED block in LDS: [comp][ell] then [5][ell]
+    int64_t stat_acc_offset; // first record of this instrument in DevScene::stat_acc (records of 8 doubles per bin ell * npix + pixel)
 };
 
 // One slot = one live photon history.  The walk kernel reads the task fields and writes the result fields; the
@@ -244,6 +245,12 @@ struct DevScene
     double* rf;
     // ---- outputs and work state
     double* frames;
+    // statistics accumulator: per instrument with statistics and per bin q = ell * npix + pixel ONE 64-byte record
+    // {sum w^0 .. sum w^4, 3 unused}, so that the five sums of a history's contribution to a bin go out with one atomic
+    // instruction whose lanes share a sector; merged into the wifu arrays of `frames` (FluxRecorder's layout) and cleared
+    // at the end of every segment (statMergeKernel)
+    double* stat_acc;
+    int64_t stat_acc_records;
     unsigned long long* counters;  // [PMC_NUM_COUNTERS]: [0..6] pmc_counter_values, [8] next history offset,
                                    // [11..31] profiling, [32 + 4 g ..] work counters of slot group g (PMC_CTR_*)
     SlotArrays slots;
@@ -252,7 +259,7 @@ struct DevScene
     //      coordinate table sits at LDS address 0 in all of them)
     int32_t lds_grid_len;          // all kernels: grid tables at offset 0
     int32_t lds_dust_off;          // transition/launch kernels: dust tables (the walk kernel keeps sigma_ext after the grid)
-    int32_t lds_src_off, lds_sed_off, lds_sed_len, lds_hot_off, lds_stat_off, lds_sort_off, lds_total_transition, lds_total_walk;
+    int32_t lds_src_off, lds_sed_off, lds_sed_len, lds_hot_off, lds_sort_off, lds_total_transition, lds_total_walk;
     int32_t dust_in_lds;
 };
 

@@ -292,6 +292,13 @@ extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBas
     return hipGetLastError();
 }
 
+// end of a segment: statistics accumulator -> wifu arrays of the frames
+extern "C" hipError_t pmcLaunchStatMerge(int slot, int blocks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(statMergeKernel, dim3(blocks), dim3(256), 0, stream, slot);
+    return hipGetLastError();
+}
+
 // transitions of the slots [slotBase, slotBase + numSlots) of slot group `group`, followed by the scan of the group's
 // ended-history counts (the launch kernel's history indices)
 extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, uint64_t seed, int maxBlocks,
