@@ -47,6 +47,7 @@
 #include "pmc_device.h"
 #include "../../include/pmc_philox.h"
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <float.h>
 #include <math.h>
 #include <algorithm>
@@ -69,6 +70,13 @@
 #ifndef PMC_PEEL_MIN_WAVES
     #define PMC_PEEL_MIN_WAVES 6  // waves per SIMD the peel-off kernel's register budget must allow (<= 80 VGPRs; it uses 75,
                                   // and must not spill: see treeSlowStep)
+#endif
+#ifndef PMC_PEEL2_MIN_WAVES
+    #define PMC_PEEL2_MIN_WAVES 4  // peel-off kernel with the next task in registers (<= 128 VGPRs)
+#endif
+#ifndef PMC_PEEL2_REFILL
+    #define PMC_PEEL2_REFILL 8  // peel-off kernel with task queues: waiting lanes that trigger a round (a round is cheap: the
+                                // records come from LDS)
 #endif
 #ifndef PMC_PROP_BLOCK
     #define PMC_PROP_BLOCK 256  // lanes per workgroup of the propagation kernel
@@ -194,6 +202,12 @@ extern "C" hipError_t pmcUploadScene(int slot, const DevScene* scene, hipStream_
 
 // the dynamic-LDS limit is a property of the kernel, not of a context: it is only ever raised (a small scene created
 // after a large one must not lower the limit under the live context)
+// LDS bytes of the task queues of one peel-off workgroup (walkPeelKernel2)
+static size_t pmcPeelQueueBytes()
+{
+    return size_t(PMC_PEEL_BLOCK / 64) * PEEL_QBYTES;
+}
+
 extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
 {
     static size_t walkMax = 0, transitionMax = 0;
@@ -205,6 +219,8 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
         size_t lds;
     } all[] = {{reinterpret_cast<const void*>(&walkPeelKernel<false>), walkMax},
                {reinterpret_cast<const void*>(&walkPeelKernel<true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPeelKernel2<false>), std::min(walkMax + 16 + pmcPeelQueueBytes(), size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPeelKernel2<true>), std::min(walkMax + 16 + pmcPeelQueueBytes(), size_t(160) * 1024)},
                {reinterpret_cast<const void*>(&walkPropKernel<false, false>), walkMax},
                {reinterpret_cast<const void*>(&walkPropKernel<false, true>), walkMax},
                {reinterpret_cast<const void*>(&walkPropKernel<true, false>), walkMax},
@@ -277,8 +293,21 @@ extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int tas
 extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, int cursor, int obs, int grid, size_t ldsBytes,
                                     hipStream_t stream)
 {
-    auto kernel = wide ? walkPeelKernel<true> : walkPeelKernel<false>;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PEEL_BLOCK), ldsBytes, stream, slot, slotBase, numSlots, cursor, obs);
+    static const bool first = getenv("PMC_PEEL_V1") != nullptr;  // (tuning aid: the form with service rounds)
+    // (an octree of 12 levels leaves no room for the task queues next to its coordinate table: service rounds)
+    if (first || ((ldsBytes + 15) & ~size_t(15)) + pmcPeelQueueBytes() > size_t(160) * 1024)
+    {
+        auto kernel = wide ? walkPeelKernel<true> : walkPeelKernel<false>;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PEEL_BLOCK), ldsBytes, stream, slot, slotBase, numSlots, cursor, obs);
+    }
+    else
+    {
+        // (the waves' task queues follow the grid tables in LDS)
+        auto kernel = wide ? walkPeelKernel2<true> : walkPeelKernel2<false>;
+        const size_t queueOffset = (ldsBytes + 15) & ~size_t(15);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PEEL_BLOCK), queueOffset + pmcPeelQueueBytes(), stream, slot, slotBase, numSlots, cursor, obs,
+                           (int)queueOffset);
+    }
     return hipGetLastError();
 }
 

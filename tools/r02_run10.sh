@@ -1,0 +1,5 @@
+export PMC_PROFILE_DUMP=1 PMC_TIMING_DUMP=1
+S="PMC_NUM_GROUPS=1,PMC_WALK_BLOCKS_PER_CU=3,PMC_SERIAL_WALKS=1"
+timeout 600 python tools/sweep.py --packets 1e8 default default,$S default,$S,PMC_PEEL_BLOCKS_PER_CU=2 default 2>&1 | grep -v "PMC_GEN\|amdgpu.ids" | tee gpurun_out/sweep10.txt
+PMC_PEEL_V1=1 timeout 600 python tools/sweep.py --packets 1e8 default default,$S default 2>&1 | grep -v "PMC_GEN\|amdgpu.ids" | tee gpurun_out/sweep10b.txt
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest10.txt 2>&1; grep -E "passed|failed|rror" gpurun_out/pytest10.txt | tail -5
