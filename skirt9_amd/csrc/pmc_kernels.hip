@@ -78,6 +78,12 @@
     #define PMC_PEEL2_REFILL 8  // peel-off kernel with task queues: waiting lanes that trigger a round (a round is cheap: the
                                 // records come from LDS)
 #endif
+#ifndef PMC_PEEL_QCAP
+    #define PMC_PEEL_QCAP 128  // task records per wave queue of the peel-off kernel (a power of two >= 128: refilled 64 at a time)
+#endif
+#ifndef PMC_PROP_TRIM
+    #define PMC_PROP_TRIM 4  // segments of a pass-1 walk recorded in LDS (pmc_walk_tree.inc walkPropKernel)
+#endif
 #ifndef PMC_PROP_BLOCK
     #define PMC_PROP_BLOCK 256  // lanes per workgroup of the propagation kernel
 #endif
@@ -221,10 +227,10 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
                {reinterpret_cast<const void*>(&walkPeelKernel<true>), walkMax},
                {reinterpret_cast<const void*>(&walkPeelKernel2<false>), std::min(walkMax + 16 + pmcPeelQueueBytes(), size_t(160) * 1024)},
                {reinterpret_cast<const void*>(&walkPeelKernel2<true>), std::min(walkMax + 16 + pmcPeelQueueBytes(), size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPropKernel<false, false>), walkMax},
-               {reinterpret_cast<const void*>(&walkPropKernel<false, true>), walkMax},
-               {reinterpret_cast<const void*>(&walkPropKernel<true, false>), walkMax},
-               {reinterpret_cast<const void*>(&walkPropKernel<true, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, true>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, true>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
                {reinterpret_cast<const void*>(&traceTreeKernel<false, false>), walkMax},
                {reinterpret_cast<const void*>(&traceTreeKernel<false, true>), walkMax},
                {reinterpret_cast<const void*>(&traceTreeKernel<true, false>), walkMax},
@@ -259,8 +265,13 @@ extern "C" int pmcWalkBlocksPerCU(int gridKind, int kind, int wide, int block, s
         e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPeelKernel<true>), block, ldsBytes)
                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPeelKernel<false>), block, ldsBytes);
     else if (gridKind == PMC_GRID_OCTREE)
+    {
+        // (with the pass-1 records of pmcLaunchProp)
+        const size_t trimOffset = (ldsBytes + 15) & ~size_t(15);
+        if (!getenv("PMC_PROP_NO_TRIM") && trimOffset + PROP_TRIM_BYTES <= size_t(160) * 1024) ldsBytes = trimOffset + PROP_TRIM_BYTES;
         e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<true, false>), block, ldsBytes)
                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<false, false>), block, ldsBytes);
+    }
     else if (gridKind == PMC_GRID_VORONOI)
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false>), block, ldsBytes);
     else
@@ -317,7 +328,12 @@ extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBas
 {
     auto kernel = wide ? (storeRf ? walkPropKernel<true, true> : walkPropKernel<true, false>)
                        : (storeRf ? walkPropKernel<false, true> : walkPropKernel<false, false>);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PROP_BLOCK), ldsBytes, stream, slot, slotBase, numSlots, cursor, seed);
+    // (the pass-1 records follow the grid tables in LDS, if there is room)
+    static const bool noTrim = getenv("PMC_PROP_NO_TRIM") != nullptr;  // (tuning aid)
+    const size_t trimOffset = (ldsBytes + 15) & ~size_t(15);
+    const bool trim = !noTrim && trimOffset + PROP_TRIM_BYTES <= size_t(160) * 1024;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PROP_BLOCK), trim ? trimOffset + PROP_TRIM_BYTES : ldsBytes, stream, slot, slotBase, numSlots, cursor,
+                       seed, trim ? (int)trimOffset : -1);
     return hipGetLastError();
 }
 
