@@ -304,7 +304,7 @@ int pmc_trace_ray(pmc_ctx* ctx, const double r[3], const double k[3], int32_t* m
 /* tuning knobs (0 = default): threads per workgroup and workgroups of the persistent walk kernel */
 int pmc_set_launch(pmc_ctx* ctx, int32_t block, int32_t grid);
 /* number of photon histories kept in flight on the device (default 8 Mi; environment PMC_NUM_SLOTS).  The slots are
-   divided into slot groups (default 2; environment PMC_NUM_GROUPS) whose generations run on separate streams */
+   divided into slot groups (default 3; environment PMC_NUM_GROUPS) whose generations run on separate streams */
 int pmc_set_num_slots(pmc_ctx* ctx, int64_t num_slots);
 /* HIP-event timing of the most recent pmc_run_primary: whole segment, sum over its walk-kernel launches, sum over
    its transition + launch kernel launches, and the number of generations (walk, transition, launch kernel triples,
