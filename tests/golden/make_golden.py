@@ -8,6 +8,8 @@
 Fixtures:
   cfg1_*       config 1 (tests/ski/cfg1.ski): 10^6 packets, seed 0, one thread -> FITS/SED/statistics files
   cfg2small_*  reduced config 2 (tests/ski/cfg2small.ski): 2x10^4 packets -> FITS/SED/statistics files
+  cfg2deep_*   the config-2 scene with a cusped dust geometry (Plummer, 60 pc; tests/ski/cfg2deep.ski): a 2318-cell octree that
+               reaches level 12 (the 21-bit index variants of the octree walk kernels) -> files, rays, cells
   cfg3small_*  reduced config 3 (tests/ski/cfg3small.ski): panchromatic, four instruments, 2x10^4 packets -> files
   cfg3z_*      the reduced config-3 scene at model redshift 0.5 (FlatUniverseCosmology) with SIX instruments, three of them in
                the observer frame (distance 0: wavelength bins at lambda (1+z), cosmological distances) -> files
@@ -99,7 +101,7 @@ def rays_config2():
 def main():
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
-    for name, scale in (("cfg1", 3.08567758e16), ("cfg1mesh", 3.08567758e16), ("cfg1mesh2", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg3small", None), ("cfg3z", None), ("cfg1nf", None),
+    for name, scale in (("cfg1", 3.08567758e16), ("cfg1mesh", 3.08567758e16), ("cfg1mesh2", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg2deep", 300 * 3.08567758e16), ("cfg3small", None), ("cfg3z", None), ("cfg1nf", None),
                         ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1sed", None), ("cfg3sed", None), ("cfg3norm", "sed"), ("cfg3disk", "sed"), ("cfg3multi", "sed"), ("cfg3flat", "sed"), ("cfg3off", "sed"), ("cfg3plum", "sed"), ("cfg1rf", "rf"), ("cfg3rf", "rf"),
                         ("cfg5small", 4000 * 3.08567758e16), ("cfg5dd", "cells"), ("cfg2shell", "cells"), ("cfg2torus", "cells"), ("cfg2ring", "cells"), ("cfg1list", "cells")):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:

@@ -40,7 +40,8 @@ def _rays(sim, n, seed, scale):
     return rays
 
 
-@pytest.mark.parametrize("name,scale", [("cfg1.ski", 3.0857e16), ("cfg1mesh.ski", 3.0857e16), ("cfg1mesh2.ski", 3.0857e16), ("cfg2small.ski", 4000 * 3.0857e16), ("cfg4small.ski", 4000 * 3.0857e16), ("cfg5small.ski", 4000 * 3.0857e16)])
+@pytest.mark.parametrize("name,scale", [("cfg1.ski", 3.0857e16), ("cfg1mesh.ski", 3.0857e16), ("cfg1mesh2.ski", 3.0857e16), ("cfg2small.ski", 4000 * 3.0857e16), ("cfg4small.ski", 4000 * 3.0857e16), ("cfg5small.ski", 4000 * 3.0857e16),
+                                        ("cfg2deep.ski", 300 * 3.0857e16)])
 def test_trace_ray_bit_exact(name, scale):
     sim = Simulation(ski(name)).setup()
     eng = _engine(sim)
@@ -82,7 +83,7 @@ def _compare_frames(sim, gpu, ref, n):
             assert a[:lay.num_lambda].sum() == n
 
 
-@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000)])
+@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000), ("cfg2deep.ski", 20000)])
 def test_photon_loop_matches_oracle(name, n):
     sim = Simulation(ski(name), num_packets=n).setup()
     eng = _engine(sim)
@@ -97,6 +98,16 @@ def test_photon_loop_matches_oracle(name, n):
     assert abs(c["cell_visits"] - counters.cell_visits) <= 1e-4 * counters.cell_visits
     assert abs(c["scatterings"] - counters.scatterings) <= 1e-4 * counters.scatterings + 2
     _compare_frames(sim, gpu, ref, n)
+
+
+def test_deep_octree_uses_the_wide_kernels():
+    """cfg2deep.ski reaches level 12: the octree walk kernels with 21-bit index fields (and, for want of LDS next to the
+    98 KB coordinate table, the peel-off kernel with service rounds and the propagation kernel without pass-1 records)"""
+    from skirt9_amd.host import scene_head
+    sim = Simulation(ski("cfg2deep.ski")).setup()
+    g = scene_head(sim).grid
+    levels = np.ctypeslib.as_array(g.node_level, (g.num_nodes,))
+    assert levels.max() == 12
 
 
 def test_partition_independence():
