@@ -925,7 +925,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     }
     HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_HISTORY, 0, sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(ctr + 32, 0, 4 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
-    HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(0, 0), 0, 8 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(0, 0), 0, 16 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(ctx->evStart, st));
     int launchBlocks = ctx->numCU * 4;  // persistent launch workgroups, as the transition kernel's
     if (const char* env = getenv("PMC_LAUNCH_BLOCKS_PER_CU")) launchBlocks = ctx->numCU * std::max(1, atoi(env));
@@ -935,7 +935,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         hipStream_t sg = ctx->groupStream[g];
         if (!initial)
         {
-            HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(g, 0), 0, 8 * sizeof(unsigned long long), sg));  // task cursors
+            HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(g, 0), 0, 16 * sizeof(unsigned long long), sg));  // task cursors
             HIP_TRY(hipEventRecord(ctx->evA[g], sg));
             if (D.grid_kind == PMC_GRID_OCTREE)
             {
@@ -1162,21 +1162,21 @@ int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out)
     {
         for (int k = 0; k < 2; ++k)
         {
-            const unsigned long long* t = host + 88 + 8 * k;
+            const unsigned long long* t = host + 208 + 8 * k;
             fprintf(stderr, "PMC_PROFILE %s phases (wave cycles): gather %llu tau+position %llu descent %llu walls %llu inside+exit %llu "
                             "service-finish+claim %llu service-loads %llu loop %llu\n", k ? "prop" : "peel", t[0], t[1], t[2], t[3], t[4], t[5],
                     t[6], t[7]);
         }
         for (int k = 0; k < 2; ++k)
         {
-            const unsigned long long* c = host + 104 + 8 * k;
+            const unsigned long long* c = host + 224 + 8 * k;
             fprintf(stderr, "PMC_PROFILE %s census (lane events): literal-algorithm steps %llu, edge %llu, descents %llu over %llu levels, octet links %llu, "
                             "hit %llu, exit %llu\n", k ? "prop" : "peel", c[0], c[2], c[3], c[4], c[5], c[6], c[7]);
         }
         fprintf(stderr, "PMC_PROFILE transition (wave cycles): stage %llu mode-load %llu cycle-tail %llu append %llu loads+detect %llu scatter %llu start-cycle %llu flush %llu\n",
-                host[40], host[41], host[42], host[43], host[44], host[45], host[46], host[47]);
+                host[192], host[193], host[194], host[195], host[196], host[197], host[198], host[199]);
         fprintf(stderr, "PMC_PROFILE launch (wave cycles): stage %llu list %llu stats-flush %llu start-cycle %llu draw+sample %llu - %llu flush %llu\n",
-                host[48], host[49], host[50], host[51], host[52], host[53], host[54]);
+                host[200], host[201], host[202], host[203], host[204], host[205], host[206]);
     }
 #endif
     return PMC_OK;

@@ -252,7 +252,8 @@ struct DevScene
     double* stat_acc;
     int64_t stat_acc_records;
     unsigned long long* counters;  // [PMC_NUM_COUNTERS]: [0..6] pmc_counter_values, [8] next history offset,
-                                   // [11..31] profiling, [32 + 4 g ..] work counters of slot group g (PMC_CTR_*)
+                                   // [16..21] walk work, [32 + 4 g ..] work counters of slot group g, [120 + g] history bases,
+                                   // [128 + 16 g ..] task cursors (PMC_CTR_*), [192..239] section timers of profiling builds
     SlotArrays slots;
     TaskArrays tasks;
     // ---- LDS carve-up (in doubles from the start of dynamic LDS; no kernel has static LDS, so that the octree
@@ -263,14 +264,14 @@ struct DevScene
     int32_t dust_in_lds;
 };
 
-#define PMC_NUM_COUNTERS 128
+#define PMC_NUM_COUNTERS 256
 #define PMC_CTR_HISTORY 8
 // [16..21] work of the octree walk kernels: peel-off wave-steps, lane-steps, service rounds; propagation likewise
 #define PMC_CTR_WALKWORK 16
 // per slot group g: live slots; cursors of the walk kernels over the slots of the group (k = 0: the generic / propagation
 // kernel, k = 1 + observer: the peel-off kernel of that observer)
 #define PMC_CTR_LIVE(g) (35 + 4 * (g))
-#define PMC_CTR_TASK(g, k) (64 + 8 * (g) + (k))
+#define PMC_CTR_TASK(g, k) (128 + 16 * (g) + (k))  // k = 0: propagation walks, 1 + i: peel-off walks towards instrument i (<= 8)
 // per slot group g: offset of the first history the group's ended slots take up this generation (endedScanKernel)
 #define PMC_CTR_HBASE(g) (120 + (g))
 #define PMC_MAX_GROUPS 4
