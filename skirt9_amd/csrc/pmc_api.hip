@@ -973,6 +973,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     // on any failure: no kernel of this segment may still be running (or be timed) when the call returns
     auto abandon = [&](int code) {
         hipDeviceSynchronize();
+        // (the statistics of the abandoned segment must not reach the frames with the next one)
+        if (D.stat_acc_records) hipMemset(D.stat_acc, 0, size_t(D.stat_acc_records) * 8 * sizeof(double));
         ctx->timed = false;
         return code;
     };
