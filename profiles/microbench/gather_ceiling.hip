@@ -1,5 +1,8 @@
 // gather_ceiling.hip -- microbenchmark: rate of dependent random 16-byte gathers (the walk step's memory operation) by
 // table size (L1-, L2-, Infinity-Cache-resident) and by the number of CUs in use: is the ceiling per CU or chip-wide?
+// FLAWED (kept for the record of round 2's first half): a pure table chase is a random mapping whose walks fall into the
+// same few cycles of ~sqrt(N) entries and then hit in L1: the rates of long runs are too high.  See gather_modes.hip /
+// gather_knee.hip, which mix the step number into the index.
 //   hipcc --offload-arch=gfx950 -O3 gather_ceiling.hip -o gather_ceiling && ./gather_ceiling
 #include <hip/hip_runtime.h>
 #include <cstdio>

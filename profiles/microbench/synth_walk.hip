@@ -2,6 +2,7 @@
 // A dependent chase through a 46 MB table of 16-byte records (one gather per step, as the walk kernels), to which the
 // features of the real step are added one at a time: f64 arithmetic that depends on the gathered record, six LDS reads
 // at record-dependent offsets, partially filled waves, a second dependent load for a fraction of the lanes.
+// FLAWED in the same way as gather_ceiling.hip (the chase falls into short cycles): see gather_modes.hip / gather_knee.hip.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off synth_walk.hip -o synth_walk && ./synth_walk
 #include <hip/hip_runtime.h>
 #include <cstdio>
