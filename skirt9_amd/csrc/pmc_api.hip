@@ -12,6 +12,7 @@
 #include "pmc_device.h"
 #include "../../include/pmc_layout.h"
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -33,7 +34,8 @@ extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int tas
 extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, int cursor, int obs, int grid, size_t ldsBytes,
                                     hipStream_t stream);
 extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, int cursor, uint64_t seed, int grid,
-                                    size_t ldsBytes, hipStream_t stream);
+                                    size_t ldsBytes, const RfLogArgs* rfLog, hipStream_t stream);
+extern "C" hipError_t pmcLaunchRfReduce(int slot, const uint32_t* keys, const double* vals, unsigned long long n, int numBuckets, hipStream_t stream);
 extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, uint64_t seed, int maxBlocks,
                                           size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int group, uint64_t first, uint64_t count,
@@ -107,6 +109,14 @@ struct pmc_ctx
     int64_t allocatedSlots{0};   // size of the allocated slot arrays
     unsigned long long* pinned{nullptr};
     unsigned long long overflowsSeen{0};  // statistics-list overflows already reported (pmc_run_primary)
+    // radiation field on an octree: per slot group the log of a generation's contributions (two buffers each for the
+    // partitioning sort) and the sort's temporary storage
+    std::vector<void*> rfAllocations;
+    uint32_t* rfKeys[PMC_MAX_GROUPS][2]{};
+    double* rfVals[PMC_MAX_GROUPS][2]{};
+    unsigned long long rfCap[PMC_MAX_GROUPS]{};
+    void* rfTemp[PMC_MAX_GROUPS]{};
+    size_t rfTempBytes{0};
 
     template<typename T> int upload(const T* host, size_t count, const T** out)
     {
@@ -485,6 +495,7 @@ void pmc_destroy(pmc_ctx* ctx)
     }
     for (void* p : ctx->allocations) hipFree(p);
     for (void* p : ctx->slotAllocations) hipFree(p);
+    for (void* p : ctx->rfAllocations) hipFree(p);
     if (ctx->pinned) hipHostFree(ctx->pinned);
     for (hipEvent_t e : {ctx->evStart, ctx->evStop})
         if (e) hipEventDestroy(e);
@@ -923,6 +934,65 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             haveWalk[g] = false;
         }
     }
+    // ---- radiation field on an octree: the contributions of a generation go to a log per slot group (pmc_device.h RfLogArgs),
+    // which is partitioned by key range and summed after the generation.  128 entries per slot (config 2: 60 per propagation
+    // walk on average); a wave that finds the log full falls back to atomic adds into the table.
+    const int64_t rfSize = ctx->rfSize;
+    const bool rfLogged = D.rf_store && D.grid_kind == PMC_GRID_OCTREE && rfSize < (int64_t(1) << 31) && getenv("PMC_RF_ATOMICS") == nullptr;
+    const int rfBuckets = rfLogged ? int((rfSize + (int64_t(1) << PMC_RF_BUCKET_BITS) - 1) >> PMC_RF_BUCKET_BITS) : 0;
+    int rfSortBits = 0;
+    while (rfBuckets > 1 && (1 << rfSortBits) < rfBuckets + 1) ++rfSortBits;  // (+ 1: the partition of the entries that fill up chunks)
+    const uint32_t rfPadKey = uint32_t(rfBuckets) << PMC_RF_BUCKET_BITS;
+    if (rfLogged)
+        for (int g = 0; g < G; ++g)
+        {
+            const unsigned long long want = ((unsigned long long)size[g] * 128ull + PMC_RF_LOG_CHUNK - 1) / PMC_RF_LOG_CHUNK * PMC_RF_LOG_CHUNK;
+            if (want <= ctx->rfCap[g]) continue;
+            HIP_TRY(hipDeviceSynchronize());
+            for (int k = 0; k < 2; ++k)
+            {
+                int rc;
+                if ((rc = ctx->allocate<uint32_t>(want, &ctx->rfKeys[g][k], false, &ctx->rfAllocations))) return rc;
+                if ((rc = ctx->allocate<double>(want, &ctx->rfVals[g][k], false, &ctx->rfAllocations))) return rc;
+            }
+            ctx->rfCap[g] = want;
+            size_t bytes = 0;
+            hipcub::DoubleBuffer<uint32_t> dk(ctx->rfKeys[g][0], ctx->rfKeys[g][1]);
+            hipcub::DoubleBuffer<double> dv(ctx->rfVals[g][0], ctx->rfVals[g][1]);
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dk, dv, (int)std::min<unsigned long long>(want, 0x7FFFFFFFull), PMC_RF_BUCKET_BITS,
+                                                       PMC_RF_BUCKET_BITS + std::max(1, rfSortBits)));
+            bytes = std::max(bytes, ctx->rfTempBytes);
+            for (int h = 0; h < PMC_MAX_GROUPS; ++h) ctx->rfTemp[h] = nullptr;  // (all groups get temporaries of the largest size)
+            ctx->rfTempBytes = bytes;
+        }
+    if (rfLogged)
+        for (int g = 0; g < G; ++g)
+            if (!ctx->rfTemp[g])
+            {
+                uint8_t* t = nullptr;
+                int rc;
+                if ((rc = ctx->allocate<uint8_t>(std::max<size_t>(ctx->rfTempBytes, 16), &t, false, &ctx->rfAllocations))) return rc;
+                ctx->rfTemp[g] = t;
+            }
+    // the log of group g (n entries claimed) -> table, on the group's stream
+    auto rfFlush = [&](int g, unsigned long long claimed) -> int {
+        const unsigned long long n = std::min(claimed, ctx->rfCap[g]);
+        if (!rfLogged || n == 0) return PMC_OK;
+        hipStream_t sg = ctx->groupStream[g];
+        const uint32_t* keys = ctx->rfKeys[g][0];
+        const double* vals = ctx->rfVals[g][0];
+        if (rfBuckets > 1)
+        {
+            hipcub::DoubleBuffer<uint32_t> dk(ctx->rfKeys[g][0], ctx->rfKeys[g][1]);
+            hipcub::DoubleBuffer<double> dv(ctx->rfVals[g][0], ctx->rfVals[g][1]);
+            size_t bytes = ctx->rfTempBytes;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ctx->rfTemp[g], bytes, dk, dv, (int)n, PMC_RF_BUCKET_BITS, PMC_RF_BUCKET_BITS + rfSortBits, sg));
+            keys = dk.Current();
+            vals = dv.Current();
+        }
+        HIP_TRY(pmcLaunchRfReduce(ctx->slot, keys, vals, n, rfBuckets, sg));
+        return PMC_OK;
+    };
     HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_HISTORY, 0, sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(ctr + 32, 0, 4 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(0, 0), 0, 16 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
@@ -935,6 +1005,9 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         hipStream_t sg = ctx->groupStream[g];
         if (!initial)
         {
+            // (the radiation-field log of the group's previous generation: its size came back with the live count)
+            if (int rc = rfFlush(g, ctx->pinned[PMC_MAX_GROUPS + g])) return rc;
+            ctx->pinned[PMC_MAX_GROUPS + g] = 0;
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(g, 0), 0, 16 * sizeof(unsigned long long), sg));  // task cursors
             HIP_TRY(hipEventRecord(ctx->evA[g], sg));
             if (D.grid_kind == PMC_GRID_OCTREE)
@@ -948,7 +1021,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                     if (!D.inst[i].same_observer)
                         HIP_TRY(pmcLaunchPeel(ctx->slot, ctx->wide, base[g], size[g], PMC_CTR_TASK(g, 1 + i), i, ctx->peelGrid, ctx->walkLds, sp));
                 HIP_TRY(hipEventRecord(ctx->evJoin[g], sp));
-                HIP_TRY(pmcLaunchProp(ctx->slot, ctx->wide, D.rf_store, base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->walkLds, sg));
+                RfLogArgs log = {ctx->rfKeys[g][0], ctx->rfVals[g][0], rfLogged ? ctx->rfCap[g] : 0ull, PMC_CTR_RFLOG(g), rfPadKey};
+                HIP_TRY(pmcLaunchProp(ctx->slot, ctx->wide, D.rf_store, base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->walkLds, &log, sg));
                 HIP_TRY(hipStreamWaitEvent(sg, ctx->evJoin[g], 0));
             }
             else
@@ -968,6 +1042,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         }
         HIP_TRY(hipEventRecord(ctx->evC[g], sg));
         HIP_TRY(hipMemcpyAsync(ctx->pinned + g, ctr + PMC_CTR_LIVE(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
+        if (rfLogged && !initial)
+            HIP_TRY(hipMemcpyAsync(ctx->pinned + PMC_MAX_GROUPS + g, ctr + PMC_CTR_RFLOG(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
         return PMC_OK;
     };
     // on any failure: no kernel of this segment may still be running (or be timed) when the call returns
@@ -1007,6 +1083,9 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             transMs += ms;
             if (ctx->pinned[g] == 0)
             {
+                // (the group's last log)
+                if (int rc = rfFlush(g, ctx->pinned[PMC_MAX_GROUPS + g])) return rc;
+                ctx->pinned[PMC_MAX_GROUPS + g] = 0;
                 active[g] = false;
                 --remaining;
                 continue;
@@ -1020,7 +1099,11 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         }
         return PMC_OK;
     };
+    for (int g = 0; g < PMC_MAX_GROUPS; ++g) ctx->pinned[PMC_MAX_GROUPS + g] = 0;
     if (int rc = drive()) return abandon(rc);
+    // (the last radiation-field logs of the groups are reduced on their streams)
+    if (rfLogged)
+        for (int g = 0; g < G; ++g) HIP_TRY(hipStreamSynchronize(ctx->groupStream[g]));
     // the segment's statistics: accumulator records -> wifu arrays (every group's stream has been waited for)
     if (D.stat_acc_records) HIP_TRY(pmcLaunchStatMerge(ctx->slot, ctx->numCU * 8, st));
     HIP_TRY(hipEventRecord(ctx->evStop, st));

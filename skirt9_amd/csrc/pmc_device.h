@@ -264,6 +264,20 @@ struct DevScene
     int32_t dust_in_lds;
 };
 
+// The radiation-field contributions of the propagation walks of one slot group and generation (octree): (key, value)
+// pairs, key = m * num_lambda + ell, appended by the walk kernel in chunks of PMC_RF_LOG_CHUNK entries that a wave claims
+// from the cursor; partitioned by key range and added to the table after the generation (pmc_api.hip rfFlush)
+struct RfLogArgs
+{
+    uint32_t* keys;
+    double* vals;
+    unsigned long long cap;  // entries; 0: no log, every contribution is an atomic add into the table
+    int32_t cursor;          // index of the log's cursor in DevScene::counters
+    uint32_t padKey;         // key of the entries that fill up a wave's last chunk (beyond every table index)
+};
+#define PMC_RF_LOG_CHUNK 4096
+#define PMC_RF_BUCKET_BITS 13  // keys per partition of the log: 2^13 doubles = 64 KB of LDS in rfReduceKernel
+
 #define PMC_NUM_COUNTERS 256
 #define PMC_CTR_HISTORY 8
 // [16..21] work of the octree walk kernels: peel-off wave-steps, lane-steps, service rounds; propagation likewise
@@ -272,6 +286,7 @@ struct DevScene
 // kernel, k = 1 + observer: the peel-off kernel of that observer)
 #define PMC_CTR_LIVE(g) (35 + 4 * (g))
 #define PMC_CTR_TASK(g, k) (128 + 16 * (g) + (k))  // k = 0: propagation walks, 1 + i: peel-off walks towards instrument i (<= 8)
+#define PMC_CTR_RFLOG(g) PMC_CTR_TASK(g, 9)        // entries of the group's radiation-field log claimed so far
 // per slot group g: offset of the first history the group's ended slots take up this generation (endedScanKernel)
 #define PMC_CTR_HBASE(g) (120 + (g))
 #define PMC_MAX_GROUPS 4

@@ -324,7 +324,7 @@ extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlo
 
 // octree: the propagation walks of the slots [slotBase, slotBase + numSlots)
 extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, int cursor, uint64_t seed, int grid,
-                                    size_t ldsBytes, hipStream_t stream)
+                                    size_t ldsBytes, const RfLogArgs* rfLog, hipStream_t stream)
 {
     auto kernel = wide ? (storeRf ? walkPropKernel<true, true> : walkPropKernel<true, false>)
                        : (storeRf ? walkPropKernel<false, true> : walkPropKernel<false, false>);
@@ -332,8 +332,25 @@ extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBas
     static const bool noTrim = getenv("PMC_PROP_NO_TRIM") != nullptr;  // (tuning aid)
     const size_t trimOffset = (ldsBytes + 15) & ~size_t(15);
     const bool trim = !noTrim && trimOffset + PROP_TRIM_BYTES <= size_t(160) * 1024;
+    RfLogArgs none = {nullptr, nullptr, 0ull, 0, 0u};
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PROP_BLOCK), trim ? trimOffset + PROP_TRIM_BYTES : ldsBytes, stream, slot, slotBase, numSlots, cursor,
-                       seed, trim ? (int)trimOffset : -1);
+                       seed, trim ? (int)trimOffset : -1, rfLog ? *rfLog : none);
+    return hipGetLastError();
+}
+
+// radiation field: the sorted (or, for a table of one partition, unsorted) log of a generation added to the table
+extern "C" hipError_t pmcLaunchRfReduce(int slot, const uint32_t* keys, const double* vals, unsigned long long n, int numBuckets, hipStream_t stream)
+{
+    static bool configured = false;
+    const size_t lds = sizeof(double) << PMC_RF_BUCKET_BITS;
+    if (!configured)
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfReduceKernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const unsigned long long blocks = (n + PMC_RF_REDUCE_SPAN - 1) / PMC_RF_REDUCE_SPAN;
+    hipLaunchKernelGGL(rfReduceKernel, dim3((unsigned)blocks), dim3(256), lds, stream, slot, keys, vals, n, (uint32_t)numBuckets);
     return hipGetLastError();
 }
 
