@@ -285,7 +285,9 @@ int pmc_download(pmc_ctx* ctx, double* host_frames, int64_t num_doubles);
 double* pmc_frames_device(pmc_ctx* ctx);
 int64_t pmc_frames_size(pmc_ctx* ctx);
 /* Radiation field table rf[m * num_lambda + ell] (doubles, W m): size (0 if the scene does not store it), device
-   pointer, copy to the host, reset to zero.  Like the frames it is ACCUMULATED into by every pmc_run_primary. */
+   pointer, copy to the host, reset to zero.  Like the frames it is ACCUMULATED into by every pmc_run_primary; it is
+   complete when the call returns.  (On an octree the engine keeps device logs of a generation's contributions, 24 bytes x
+   128 entries per packet slot, instead of adding each one atomically; environment PMC_RF_ATOMICS selects the atomics.) */
 int64_t pmc_radiation_field_size(pmc_ctx* ctx);
 double* pmc_radiation_field_device(pmc_ctx* ctx);
 /* caller-owned DEVICE memory for the table (num_doubles f64, zero-initialised by the caller), e.g. a torch tensor */

@@ -946,7 +946,10 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     if (rfLogged)
         for (int g = 0; g < G; ++g)
         {
-            const unsigned long long want = ((unsigned long long)size[g] * 128ull + PMC_RF_LOG_CHUNK - 1) / PMC_RF_LOG_CHUNK * PMC_RF_LOG_CHUNK;
+            unsigned long long perSlot = 128ull;
+            if (const char* env = getenv("PMC_RF_LOG_PER_SLOT")) perSlot = std::max(1, atoi(env));  // (tests: a log that overflows)
+            const unsigned long long want = std::max<unsigned long long>(((unsigned long long)size[g] * perSlot + PMC_RF_LOG_CHUNK - 1) / PMC_RF_LOG_CHUNK, 1ull)
+                                            * PMC_RF_LOG_CHUNK;
             if (want <= ctx->rfCap[g]) continue;
             HIP_TRY(hipDeviceSynchronize());
             for (int k = 0; k < 2; ++k)

@@ -165,6 +165,27 @@ def test_radiation_field_matches_oracle(name, n):
     assert eng.download_radiation_field().sum() == 0.
 
 
+def test_radiation_field_log_overflow_falls_back_to_atomics(monkeypatch):
+    """octree: the contributions of a generation go to a log of 128 entries per slot; with one entry per slot most waves find
+    the log full and add their contributions atomically -- the table must not change (same tolerances as above)"""
+    n = 20000
+    monkeypatch.setenv("PMC_RF_LOG_PER_SLOT", "1")
+    sim = Simulation(ski("cfg3rf.ski"), num_packets=n).setup()
+    eng = _engine(sim)
+    eng.run_primary(0, n, 5)
+    small = eng.download_radiation_field()
+    monkeypatch.delenv("PMC_RF_LOG_PER_SLOT")
+    monkeypatch.setenv("PMC_RF_ATOMICS", "1")
+    eng2 = _engine(sim)
+    eng2.run_primary(0, n, 5)
+    atomics = eng2.download_radiation_field()
+    _, ref_rf, _ = O.run_primary_rf(sim, 0, n, O.RNG_PHILOX, seed=5)
+    for got in (small, atomics):
+        assert abs(got.sum() - ref_rf.sum()) <= 1e-9 * ref_rf.sum()
+        assert np.array_equal(got > 0, ref_rf > 0)
+        assert (np.abs(got - ref_rf) > 1e-6 * np.abs(ref_rf) + 1e-13 * ref_rf.max()).sum() == 0
+
+
 def test_radiation_field_absent_unless_requested():
     sim = Simulation(ski("cfg1.ski"), num_packets=1000).setup()
     eng = _engine(sim)
