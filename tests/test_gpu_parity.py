@@ -110,6 +110,26 @@ def test_deep_octree_uses_the_wide_kernels():
     assert levels.max() == 12
 
 
+def test_eight_observers_and_three_slot_groups():
+    """cfg3eight.ski: eight instruments with eight different observers (eight peel-off walk kernels per generation, each with
+    its own task cursor) at a packet count that gives three slot groups -- frames against the oracle on the same histories"""
+    n = 250000
+    sim = Simulation(ski("cfg3eight.ski"), num_packets=n).setup()
+    eng = _engine(sim)
+    eng.run_primary(0, n, 3)
+    gpu = eng.download()
+    ref, counters = O.run_primary(sim, 0, n, O.RNG_PHILOX, seed=3)
+    c = eng.counters()
+    assert c["histories"] == n and c["stat_overflows"] == 0
+    assert abs(c["cell_visits"] - counters.cell_visits) <= 1e-4 * counters.cell_visits
+    assert eng.last_timing()["generations"] > 20
+    tot = np.abs(ref).sum()
+    assert abs(gpu.sum() - ref.sum()) <= 1e-9 * tot
+    scale = np.abs(ref).max()
+    bad = np.abs(gpu - ref) > (1e-6 * np.abs(ref) + 1e-12 * scale)
+    assert bad.sum() <= max(4, 1e-3 * np.count_nonzero(ref)), int(bad.sum())
+
+
 def test_partition_independence():
     """histories are keyed by index: two launches over [0,n/2) and [n/2,n) give the same frames as one over [0,n)"""
     n = 8000
