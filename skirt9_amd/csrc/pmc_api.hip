@@ -623,6 +623,57 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
             }
             if ((rc = ctx->upload(pair.data(), pair.size(), &D.vpair))) return bail(rc);
         }
+        D.vcull = nullptr;
+        if (!getenv("PMC_VORO_NO_CULL"))
+        {
+            // neighbours that no direction of a cone can leave the cell through (DevScene::vcull).  A cone = the directions with
+            // one sign pattern and one order of |k_x|, |k_y|, |k_z|: the non-negative combinations of three extreme rays, so
+            // n . k <= 0 on the cone <=> n . e <= 0 for the three rays; the margin (1e-9 |n| |e|) is far above the rounding of
+            // the kernel's n . k.
+            static const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+            const int ncell = g.num_cells;
+            std::vector<unsigned long long> cull(size_t(ncell) * 48, 0ull);
+            for (int m = 0; m < ncell; ++m)
+                for (int q = g.vnbr_start[m]; q < g.vnbr_start[m + 1] && q - g.vnbr_start[m] < 64; ++q)
+                {
+                    const int j = q - g.vnbr_start[m];
+                    const int mi = g.vnbr_list[q];
+                    double nv[3] = {0., 0., 0.};
+                    double norm = 0.;
+                    if (mi >= 0)
+                    {
+                        for (int a = 0; a < 3; ++a) nv[a] = g.site[3 * size_t(mi) + a] - g.site[3 * size_t(m) + a];
+                        norm = std::sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+                    }
+                    for (int sgn = 0; sgn < 8; ++sgn)
+                        for (int p = 0; p < 6; ++p)
+                        {
+                            bool skip;
+                            if (mi >= 0)
+                            {
+                                double e[3] = {0., 0., 0.};
+                                skip = norm > 0.;
+                                for (int r = 0; r < 3 && skip; ++r)
+                                {
+                                    const int a = perm[p][r];
+                                    e[a] = ((sgn >> a) & 1) ? -1. : 1.;
+                                    const double dot = nv[0] * e[0] + nv[1] * e[1] + nv[2] * e[2];
+                                    if (!(dot <= -1e-9 * norm * 2.)) skip = false;
+                                }
+                            }
+                            else
+                            {
+                                // walls -1 .. -6: x min, x max, y min, y max, z min, z max (reached only by k_a < 0 / k_a > 0)
+                                const int wall = -mi - 1;
+                                if (wall > 5) continue;
+                                const bool negative = ((sgn >> (wall >> 1)) & 1) != 0;
+                                skip = (wall & 1) ? negative : !negative;
+                            }
+                            if (skip) cull[size_t(m) * 48 + sgn * 6 + p] |= 1ull << j;
+                        }
+                }
+            if ((rc = ctx->upload(cull.data(), cull.size(), &D.vcull))) return bail(rc);
+        }
         D.vblock_n = g.vblock_n;
         if ((rc = ctx->upload(g.vblock_start, nb3 + 1, &D.vblock_start))) return bail(rc);
         if ((rc = ctx->upload(g.vblock_list, size_t(g.vblock_start[nb3]), &D.vblock_list))) return bail(rc);

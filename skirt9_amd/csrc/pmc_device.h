@@ -216,6 +216,10 @@ struct DevScene
     const double* vpair;          // [vnbr_start[num_cells]][4]: per (cell, neighbour) entry the neighbour's site x, y, z and its
                                   // index (as the bit pattern of an int64), in list order: the hot loop reads two 16-byte
                                   // words per neighbour from consecutive addresses instead of index -> site gathers
+    const unsigned long long* vcull;  // [num_cells][48]: per cell and direction cone (sign pattern of k x order of |k_x|, |k_y|,
+                                  // |k_z|) bit j set: the j-th neighbour of the list (j < 64) lies behind every direction of the
+                                  // cone (n . k < 0 with a margin far above rounding), or is a domain wall the cone moves away
+                                  // from: the reference skips it (ndotk > 0 fails), and the walk does not even read it
     int32_t vblock_n;
     const int32_t* vblock_start;  // [vblock_n^3 + 1]
     const int32_t* vblock_list;

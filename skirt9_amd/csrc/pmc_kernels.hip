@@ -103,6 +103,9 @@
 #ifndef PMC_VORO_UNROLL
     #define PMC_VORO_UNROLL 8  // Voronoi walk: neighbours whose gathers are in flight together (pmc_walk.inc voroEnter)
 #endif
+#ifndef PMC_VORO_CULL_ROUND
+    #define PMC_VORO_CULL_ROUND 6  // Voronoi walk: neighbours per round of the masked exit search
+#endif
 #ifndef PMC_WALK_STEPS
     #define PMC_WALK_STEPS 4  // steps between two service checks
 #endif
