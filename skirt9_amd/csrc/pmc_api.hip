@@ -631,8 +631,12 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
             // n . k <= 0 on the cone <=> n . e <= 0 for the three rays; the margin (1e-9 |n| |e|) is far above the rounding of
             // the kernel's n . k.
             static const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+            // every cone is divided once more at the midpoints of its edges (PMC_VORO_CONES = 192: four sub-cones, the rays
+            // e1, e1 + e2, e1 + e3 | e2, e1 + e2, e2 + e3 | e3, e1 + e3, e2 + e3 | e1 + e2, e1 + e3, e2 + e3)
+            static const int sub[4][3][3] = {{{1, 0, 0}, {1, 1, 0}, {1, 0, 1}}, {{0, 1, 0}, {1, 1, 0}, {0, 1, 1}}, {{0, 0, 1}, {1, 0, 1}, {0, 1, 1}},
+                                             {{1, 1, 0}, {1, 0, 1}, {0, 1, 1}}};
             const int ncell = g.num_cells;
-            std::vector<unsigned long long> cull(size_t(ncell) * 48, 0ull);
+            std::vector<unsigned long long> cull(size_t(ncell) * PMC_VORO_CONES, 0ull);
             for (int m = 0; m < ncell; ++m)
                 for (int q = g.vnbr_start[m]; q < g.vnbr_start[m + 1] && q - g.vnbr_start[m] < 64; ++q)
                 {
@@ -648,28 +652,35 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
                     for (int sgn = 0; sgn < 8; ++sgn)
                         for (int p = 0; p < 6; ++p)
                         {
-                            bool skip;
-                            if (mi >= 0)
+                            // the extreme rays of the cone: e1 along the largest component, e2 = e1 + the second, e3 = e2 + the third
+                            double e[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
+                            for (int r = 0; r < 3; ++r)
+                                for (int t = r; t < 3; ++t) e[t][perm[p][r]] = ((sgn >> perm[p][r]) & 1) ? -1. : 1.;
+                            for (int c = 0; c < PMC_VORO_CONES / 48; ++c)
                             {
-                                double e[3] = {0., 0., 0.};
-                                skip = norm > 0.;
-                                for (int r = 0; r < 3 && skip; ++r)
+                                bool skip;
+                                if (mi >= 0)
                                 {
-                                    const int a = perm[p][r];
-                                    e[a] = ((sgn >> a) & 1) ? -1. : 1.;
-                                    const double dot = nv[0] * e[0] + nv[1] * e[1] + nv[2] * e[2];
-                                    if (!(dot <= -1e-9 * norm * 2.)) skip = false;
+                                    skip = norm > 0.;
+                                    for (int r = 0; r < 3 && skip; ++r)
+                                    {
+                                        double ray[3];
+                                        for (int a = 0; a < 3; ++a)
+                                            ray[a] = PMC_VORO_CONES == 48 ? e[r][a] : sub[c][r][0] * e[0][a] + sub[c][r][1] * e[1][a] + sub[c][r][2] * e[2][a];
+                                        const double dot = nv[0] * ray[0] + nv[1] * ray[1] + nv[2] * ray[2];
+                                        if (!(dot <= -1e-9 * norm * 4.)) skip = false;
+                                    }
                                 }
+                                else
+                                {
+                                    // walls -1 .. -6: x min, x max, y min, y max, z min, z max (reached only by k_a < 0 / k_a > 0)
+                                    const int wall = -mi - 1;
+                                    if (wall > 5) continue;
+                                    const bool negative = ((sgn >> (wall >> 1)) & 1) != 0;
+                                    skip = (wall & 1) ? negative : !negative;
+                                }
+                                if (skip) cull[size_t(m) * PMC_VORO_CONES + (sgn * 6 + p) * (PMC_VORO_CONES / 48) + c] |= 1ull << j;
                             }
-                            else
-                            {
-                                // walls -1 .. -6: x min, x max, y min, y max, z min, z max (reached only by k_a < 0 / k_a > 0)
-                                const int wall = -mi - 1;
-                                if (wall > 5) continue;
-                                const bool negative = ((sgn >> (wall >> 1)) & 1) != 0;
-                                skip = (wall & 1) ? negative : !negative;
-                            }
-                            if (skip) cull[size_t(m) * 48 + sgn * 6 + p] |= 1ull << j;
                         }
                 }
             if ((rc = ctx->upload(cull.data(), cull.size(), &D.vcull))) return bail(rc);

@@ -216,7 +216,7 @@ struct DevScene
     const double* vpair;          // [vnbr_start[num_cells]][4]: per (cell, neighbour) entry the neighbour's site x, y, z and its
                                   // index (as the bit pattern of an int64), in list order: the hot loop reads two 16-byte
                                   // words per neighbour from consecutive addresses instead of index -> site gathers
-    const unsigned long long* vcull;  // [num_cells][48]: per cell and direction cone (sign pattern of k x order of |k_x|, |k_y|,
+    const unsigned long long* vcull;  // [num_cells][PMC_VORO_CONES]: per cell and direction cone (sign pattern of k x order of |k_x|, |k_y|,
                                   // |k_z|) bit j set: the j-th neighbour of the list (j < 64) lies behind every direction of the
                                   // cone (n . k < 0 with a margin far above rounding), or is a domain wall the cone moves away
                                   // from: the reference skips it (ndotk > 0 fails), and the walk does not even read it
@@ -279,6 +279,9 @@ struct RfLogArgs
     int32_t cursor;          // index of the log's cursor in DevScene::counters
     uint32_t padKey;         // key of the entries that fill up a wave's last chunk (beyond every table index)
 };
+#ifndef PMC_VORO_CONES
+#define PMC_VORO_CONES 192  // direction cones of DevScene::vcull: 48, or 192 (every cone divided at the midpoints of its edges)
+#endif
 #define PMC_RF_LOG_CHUNK 4096
 #define PMC_RF_BUCKET_BITS 13  // keys per partition of the log: 2^13 doubles = 64 KB of LDS in rfReduceKernel
 
