@@ -623,6 +623,18 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
             }
             if ((rc = ctx->upload(pair.data(), pair.size(), &D.vpair))) return bail(rc);
         }
+        {
+            // the header record of a cell (DevScene::vhead)
+            std::vector<double> head(8 * size_t(g.num_cells), 0.);
+            for (int m = 0; m < g.num_cells; ++m)
+            {
+                for (int a = 0; a < 3; ++a) head[8 * size_t(m) + a] = g.site[3 * size_t(m) + a];
+                head[8 * size_t(m) + 3] = scene->medium.number_density[m];
+                const int32_t bounds[2] = {g.vnbr_start[m], g.vnbr_start[m + 1]};
+                std::memcpy(&head[8 * size_t(m) + 4], bounds, sizeof(double));
+            }
+            if ((rc = ctx->upload(head.data(), head.size(), &D.vhead))) return bail(rc);
+        }
         D.vcull = nullptr;
         if (!getenv("PMC_VORO_NO_CULL"))
         {

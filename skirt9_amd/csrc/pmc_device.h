@@ -216,6 +216,8 @@ struct DevScene
     const double* vpair;          // [vnbr_start[num_cells]][4]: per (cell, neighbour) entry the neighbour's site x, y, z and its
                                   // index (as the bit pattern of an int64), in list order: the hot loop reads two 16-byte
                                   // words per neighbour from consecutive addresses instead of index -> site gathers
+    const double* vhead;          // [num_cells][8]: per cell ONE 64-byte record {site x, y, z, number density, list start | list end
+                                  // (two int32 in one double), 3 unused}: what a walk reads of the cell it enters, in one sector
     const unsigned long long* vcull;  // [num_cells][PMC_VORO_CONES]: per cell and direction cone (sign pattern of k x order of |k_x|, |k_y|,
                                   // |k_z|) bit j set: the j-th neighbour of the list (j < 64) lies behind every direction of the
                                   // cone (n . k < 0 with a margin far above rounding), or is a domain wall the cone moves away
