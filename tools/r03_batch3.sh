@@ -1,0 +1,18 @@
+#!/bin/bash
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out/r03_batch3; mkdir -p $O
+S="PMC_NUM_GROUPS=1,PMC_SERIAL_WALKS=1,PMC_TIMING_DUMP=1"
+python tools/sweep.py --packets 5e7 \
+  default,$S,PMC_WALK_BLOCKS_PER_CU=3 \
+  libpmc_pert_gather_3.so,$S,PMC_WALK_BLOCKS_PER_CU=3 \
+  libpmc_pert_gather_4.so,$S,PMC_WALK_BLOCKS_PER_CU=3 \
+  libpmc_pert_gather_3.so,$S,PMC_WALK_BLOCKS_PER_CU=1 \
+  libpmc_pert_gather_4.so,$S,PMC_WALK_BLOCKS_PER_CU=1 \
+  > $O/sweep.txt 2>&1
+python tools/sweep.py --packets 5e7 --ski tests/ski/cfg2small.ski \
+  default,$S,PMC_WALK_BLOCKS_PER_CU=3 \
+  libpmc_pert_gather_2.so,$S,PMC_WALK_BLOCKS_PER_CU=3 \
+  libpmc_pert_valu_96.so,$S,PMC_WALK_BLOCKS_PER_CU=3 \
+  >> $O/sweep.txt 2>&1
+grep -v "amdgpu.ids" $O/sweep.txt | tail -40
