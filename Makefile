@@ -46,3 +46,10 @@ host: skirt9_amd/lib/libskirthost.so
 clean:
 	rm -rf skirt9_amd/lib oracle/_build
 .PHONY: all oracle host clean
+
+# tuning aid: a variant of the engine with extra definitions (tools/sweep.py picks it by file name), e.g.
+#   make variant NAME=pert_valu_48 DEFS=-DPMC_PERTURB_VALU=48     -> skirt9_amd/lib/libpmc_pert_valu_48.so
+variant:
+	@mkdir -p skirt9_amd/lib
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -shared $(wildcard skirt9_amd/csrc/*.hip) -lrccl -o skirt9_amd/lib/libpmc_$(NAME).so
+.PHONY: variant

@@ -7,8 +7,10 @@ FullInstrument 512^2 with component + statistics recording, 10^8 packets per ste
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one segment: every rank runs P histories of its own index range through the HIP engine and the
-detector frames of all ranks are summed onto rank 0 with ONE RCCL reduce (the counterpart of
-ProcessManager::sumToRoot at FluxRecorder.cpp:487-493).  Inputs (grid, densities, tables) are resident in HBM
+detector frames of all ranks are summed onto rank 0 with ONE RCCL reduce -- the engine library's own
+pmc_reduce_frames over the communicator it built with pmc_comm_init_rank (the counterpart of
+ProcessManager::sumToRoot at FluxRecorder.cpp:487-493); torch.distributed is the control plane only (hands the
+communicator id to the ranks, barrier, maximum of the ranks' times).  Inputs (grid, densities, tables) are resident in HBM
 before the timed region.  Prints one JSON line (rank 0).
 
 roofline: HBM-bound walk.  achieved = algorithmic bytes of one step (V*20 + U*8 with V = cell visits and U = detector
@@ -33,6 +35,8 @@ sys.path.insert(0, ROOT)
 
 SKI = os.path.join(ROOT, "tests", "ski", "cfg2.ski")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+VORONOI_KEPT_NEIGHBOURS = 0.60  # fraction of a Voronoi cell's neighbours the walk reads after the cone cull
+GATHER_CEILING = 2.1e11  # dependent random 32-byte gathers per second through a 32 MB table at 12-14 waves per CU (measured)
 
 
 def pmc_traffic(packets_per_step):
@@ -143,6 +147,23 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    # the data path of N > 1: the PRODUCT's RCCL communicator (include/pmc.h pmc_comm_*), one rank per process.  Rank 0
+    # draws the id, the control plane hands it to the others.
+    comm = None
+    nccl_ranks = 1
+    # (BENCH_FORCE_COMM=1: also with one rank -- a one-rank communicator walks the same calls on a one-GPU box)
+    if (world > 1 and not share) or (world == 1 and os.environ.get("BENCH_FORCE_COMM") == "1"):
+        from skirt9_amd.engine import Communicator
+        ident = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        if rank == 0:
+            ident.copy_(torch.frombuffer(bytearray(Communicator.unique_id()), dtype=torch.uint8))
+        if world > 1:
+            dist.broadcast(ident, src=0)
+        comm = Communicator.rank(local_rank, world, rank, bytes(ident.cpu().numpy().tobytes()))
+        nccl_ranks, my_rank = comm.size()
+        if nccl_ranks != world or my_rank != rank:
+            raise SystemExit(f"RCCL communicator reports {nccl_ranks} ranks / rank {my_rank}, expected {world} / {rank}")
+
     P = int(args.packets)
     total_per_step = P if args.strong else P * world
     if world > 1:
@@ -186,7 +207,7 @@ def main():
         rf_ski = os.path.join(tempfile.mkdtemp(prefix=f"bench_rf_r{rank}_"), os.path.basename(ski_path))
         open(rf_ski, "w").write(text.replace('storeRadiationField="false"', 'storeRadiationField="true"'))
         ski_path = rf_ski
-    from skirt9_amd.distributed import history_range
+    from skirt9_amd.engine import history_range
     from skirt9_amd.host import scene_head
 
     def fence():
@@ -220,16 +241,21 @@ def main():
             first, count = history_range(total_per_step, rank, world)
             eng.run_primary(index * total_per_step + first, count, seed)
             eng.sync()
-            if world > 1:
-                if share:
-                    dist.all_reduce(frames, op=dist.ReduceOp.SUM)  # (gloo has no GPU reduce)
-                else:
-                    dist.reduce(frames, dst=0, op=dist.ReduceOp.SUM)
+            if comm is not None:
+                # ONE ncclReduce of the bound frames onto rank 0 on the engine's stream; the other ranks' frames are cleared
+                # (pmc_reduce_frames returns when the reduce is complete)
+                eng.reduce_frames(comm.handles[0], 0)
+                if rf is not None:
+                    eng.allreduce_radiation_field(comm.handles[0])
+                    rf.zero_()      # (a benchmark step is a whole segment: what follows would consume the field here)
+            elif world > 1:
+                # (BENCH_SHARE_DEVICE: all ranks on one device, exchange over gloo -- a flow check, RCCL refuses it)
+                dist.all_reduce(frames, op=dist.ReduceOp.SUM)
                 if rank != 0:
-                    frames.zero_()  # rank 0 holds the sum so far; the others start the next segment from zero
+                    frames.zero_()
                 if rf is not None:
                     dist.all_reduce(rf, op=dist.ReduceOp.SUM)
-                    rf.zero_()      # (a benchmark step is a whole segment: what follows would consume the field here)
+                    rf.zero_()
 
         for w in range(warmup):
             step(w)
@@ -242,6 +268,7 @@ def main():
             step(warmup + k)
             t = eng.last_timing()
             t["walk_ms"] = eng.last_kernel_ms()  # HIP events around every walk-kernel launch of the segment, summed
+            t.update(eng.last_walk_timing())     # octree: the peel-off and the propagation kernels apart
             timings.append(t)
         fence()
         elapsed = time.perf_counter() - t0
@@ -250,13 +277,45 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         counters = eng.counters()
+        walk_work = eng.walk_work()
+        # outside the timed region: one more (small) segment whose reduce is checked -- what rank 0 holds afterwards is the
+        # sum of what the ranks held before it.  wsed[0] (histories per wavelength bin that reached the first instrument's
+        # SED) is a table of integer counts, so the comparison is exact.
+        reduce_check = None
+        if world > 1 or comm is not None:
+            frames.zero_()
+            torch.cuda.synchronize()
+            n_check = 200000 * world
+            first, count = history_range(n_check, rank, world)
+            eng.run_primary((warmup + steps) * total_per_step + first, count, seed)
+            eng.sync()
+            lay = sim.layout(0)
+            part = frames[lay.wsed_offset:lay.wsed_offset + lay.num_lambda] if lay.wsed_offset >= 0 else frames
+            before = part.sum().reshape(1).clone()
+            if world > 1:
+                dist.all_reduce(before, op=dist.ReduceOp.SUM)
+            if comm is not None:
+                eng.reduce_frames(comm.handles[0], 0)
+            else:
+                dist.all_reduce(frames, op=dist.ReduceOp.SUM)
+            after = float(part.sum().item())
+            want = float(before.item())
+            exact = lay.wsed_offset >= 0
+            if rank == 0 and (after != want if exact else abs(after - want) > 1e-9 * abs(want)):
+                raise SystemExit(f"reduce check failed: rank 0 holds {after!r} after the reduce, the ranks held {want!r} before it")
+            reduce_check = {"quantity": "sum of wsed[0] of the first instrument (integer counts)" if exact else "sum of the frames",
+                            "histories": n_check, "rank0_after_reduce": after, "sum_over_ranks_before": want}
         grid = scene_head(sim).grid
         result = {"elapsed": elapsed, "timings": timings, "counters": counters, "cells": int(grid.num_cells), "steps": steps,
+                  "reduce_check": reduce_check, "walk_work": walk_work,
                   "packets_this_rank": history_range(total_per_step, rank, world)[1],
                   "vnbr_mean": (grid.vnbr_start[grid.num_cells] / grid.num_cells) if args.config == 5 else None}
         eng.close()
         del frames, rf
         return result
+
+    def mean_ms_of(m):
+        return sum(t["total_ms"] for t in m["timings"]) / len(m["timings"])
 
     def roofline_of(m):
         """algorithmic bytes of one step of this rank (V * bytes per visit + U * 8, V and U COUNTED by the kernels) over the
@@ -269,12 +328,33 @@ def main():
             # Voronoi: a visit reads the cell's own record (site + density, 32 B) and, for each of its neighbours, the
             # neighbour index (4 B) and the neighbour's site (24 B) -- VoronoiMeshSnapshot.cpp:1096-1150; the mean
             # neighbour count is taken over the cells of the mesh (15.2 for tests/ski/cfg5.ski)
-            bytes_per_visit = 32.0 + 28.0 * m["vnbr_mean"]
+            # the walk skips the neighbours that lie behind every direction of the walk's direction cone (DevScene::vcull, 192
+            # cones: 40 % of the neighbours of tests/ski/cfg5.ski): only the bytes of the neighbours it
+            # has to read count, so that `frac` cannot exceed what is read
+            bytes_per_visit = 32.0 + 28.0 * m["vnbr_mean"] * VORONOI_KEPT_NEIGHBOURS
         n = max(1, m["packets_this_rank"])
         bytes_per_launch = bytes_per_visit * V + 8.0 * U
         mean_ms = sum(t["total_ms"] for t in m["timings"]) / len(m["timings"])
         achieved = bytes_per_launch / (mean_ms * 1e-3) / 1e9
-        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        extra = {}
+        w = m["walk_work"]
+        if w["prop_wave_steps"] and w["peel_wave_steps"]:
+            # octree: secondary yardsticks.  A lane-step is one cell visit by one lane (first pass, second pass and peel-off
+            # walks alike): one dependent 32-byte gather.  gather_frac prices the whole step against the measured rate of
+            # dependent random 32-byte gathers through a 32 MB table on this chip (GATHER_CEILING, profiles/microbench/
+            # gather_knee_mi355x.txt); the per-kernel figures divide each kernel's own work by its own span (the spans of the
+            # two kernels overlap on two streams, and with the other slot groups' kernels).
+            peel_ms = sum(t["peel_ms"] for t in m["timings"]) / len(m["timings"])
+            prop_ms = sum(t["prop_ms"] for t in m["timings"]) / len(m["timings"])
+            peel_ls, prop_ls = w["peel_lane_steps"] / launches, w["prop_lane_steps"] / launches
+            extra = {"gather_frac": (peel_ls + prop_ls) / (mean_ms_of(m) * 1e-3) / GATHER_CEILING,
+                     "gather_ceiling": GATHER_CEILING, "gather_ceiling_source": "profiles/microbench/gather_knee_mi355x.txt",
+                     "lane_steps_per_packet": (peel_ls + prop_ls) / n,
+                     "prop": {"span_ms": prop_ms, "lane_steps_per_s": prop_ls / (prop_ms * 1e-3), "frac": 20.0 * prop_ls / (prop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "lanes_in_use": w["prop_lane_steps"] / (64.0 * w["prop_wave_steps"])},
+                     "peel": {"span_ms": peel_ms, "lane_steps_per_s": peel_ls / (peel_ms * 1e-3), "frac": 20.0 * peel_ls / (peel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "lanes_in_use": w["peel_lane_steps"] / (64.0 * w["peel_wave_steps"])}}
+        return {**extra, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "kernel_ms": mean_ms, "segment_ms": mean_ms,
                 "walk_kernel_ms_sum": sum(t["walk_ms"] for t in m["timings"]) / len(m["timings"]),
                 "transition_kernel_ms": sum(t["transition_ms"] for t in m["timings"]) / len(m["timings"]),
@@ -339,6 +419,13 @@ def main():
                        "parallelism": f"history-range x{world}"},
             "roofline": roof,
         }
+        if world > 1 or comm is not None:
+            # what summed the ranks' detector arrays, and what RCCL itself reports about the communicator
+            out["reduce"] = ("pmc_reduce_frames: one ncclReduce (f64, sum) per step on the engine's stream, communicator built by the "
+                             "engine library (pmc_comm_unique_id / pmc_comm_init_rank)") if comm is not None else \
+                            "torch.distributed all_reduce over gloo (BENCH_SHARE_DEVICE flow check: all ranks on one device)"
+            out["nccl_ranks"] = nccl_ranks if comm is not None else 0
+            out["reduce_check"] = main_run["reduce_check"]
         if secondary is not None:
             sroof = roofline_of(secondary)
             out["secondary"] = {"workload": "the same octree with a UniformBoxGeometry source of +-10 x +-10 x +-1 kpc (north_star's second "
@@ -353,6 +440,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -312,6 +312,21 @@ int pmc_set_num_slots(pmc_ctx* ctx, int64_t num_slots);
    its transition + launch kernel launches, and the number of generations (walk, transition, launch kernel triples,
    counted over all slot groups) */
 int pmc_last_timing(pmc_ctx* ctx, float* total_ms, float* walk_ms, float* transition_ms, int32_t* generations);
+/* octree grids: the two kinds of walk kernel of the most recent pmc_run_primary apart -- the spans of the peel-off kernels
+   (MediumSystem::getExtinctionOpticalDepth, all observers) and of the propagation kernel
+   (MediumSystem::setExtinctionOpticalDepths + the interaction point), HIP events, summed over the generations; the two run
+   side by side on two streams of a slot group, so the spans overlap.  0 on other grids. */
+int pmc_last_walk_timing(pmc_ctx* ctx, float* peel_ms, float* prop_ms);
+/* counted work of the octree walk kernels since create/reset: a wave-step is one pass of a wavefront through the step
+   code, a lane-step one cell visit by one lane (lane_steps / (64 wave_steps) = the fraction of the lanes that held a walk);
+   rounds = bookkeeping rounds (finished walks stored, next walks taken up).  Propagation lane-steps include the second
+   pass over a forced-scattering path.  No reference counterpart (roofline inputs). */
+typedef struct pmc_walk_work_values
+{
+    uint64_t peel_wave_steps, peel_lane_steps, peel_rounds;
+    uint64_t prop_wave_steps, prop_lane_steps, prop_rounds;
+} pmc_walk_work_values;
+int pmc_walk_work(pmc_ctx* ctx, pmc_walk_work_values* out);
 
 /* ---------------------------------------------------------------- several GPUs: one segment over RCCL ---- */
 
@@ -328,6 +343,8 @@ void pmc_history_range(uint64_t num_packets, int32_t rank, int32_t num_ranks, ui
 int  pmc_comm_init_all(int32_t num_devices, const int32_t* devices, void** comms);
 int  pmc_comm_unique_id(void* unique_id);
 int  pmc_comm_init_rank(int32_t device, int32_t num_ranks, int32_t rank, const void* unique_id, void** comm);
+/* ranks of the communicator and the rank of this handle in it, as RCCL reports them (ncclCommCount, ncclCommUserRank) */
+int  pmc_comm_size(void* comm, int32_t* num_ranks, int32_t* rank);
 void pmc_comm_destroy(void* comm);
 
 /* End of a segment: the detector arrays of all ranks are summed onto `root` with ONE ncclReduce (f64, sum) on the

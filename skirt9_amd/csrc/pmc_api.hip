@@ -88,10 +88,11 @@ struct pmc_ctx
     hipStream_t groupStream[PMC_MAX_GROUPS]{};
     // octree: the peel-off kernels of a generation run on a side stream of the group, next to its propagation kernel
     hipStream_t peelStream[PMC_MAX_GROUPS]{};
-    hipEvent_t evA[PMC_MAX_GROUPS]{}, evB[PMC_MAX_GROUPS]{}, evC[PMC_MAX_GROUPS]{}, evJoin[PMC_MAX_GROUPS]{};
+    hipEvent_t evA[PMC_MAX_GROUPS]{}, evB[PMC_MAX_GROUPS]{}, evC[PMC_MAX_GROUPS]{}, evJoin[PMC_MAX_GROUPS]{}, evProp[PMC_MAX_GROUPS]{};
     hipEvent_t evStart{nullptr}, evStop{nullptr};
     bool timed{false};
     float totalMs{0}, walkMs{0}, transitionMs{0};
+    float peelMs{0}, propMs{0};  // octree: the spans of the peel-off kernels and of the propagation kernel, summed over the generations
     int generations{0};
     DevScene dev{};
     std::vector<void*> allocations;
@@ -109,6 +110,8 @@ struct pmc_ctx
     int64_t allocatedSlots{0};   // size of the allocated slot arrays
     unsigned long long* pinned{nullptr};
     unsigned long long overflowsSeen{0};  // statistics-list overflows already reported (pmc_run_primary)
+    int32_t* statPoolIota{nullptr};       // 0, 1, 2, ...: the free list of a statistics pool none of whose blocks is in use
+    int64_t statPoolBlocks{0};
     // radiation field on an octree: per slot group the log of a generation's contributions (two buffers each for the
     // partitioning sort) and the sort's temporary storage
     std::vector<void*> rfAllocations;
@@ -438,12 +441,32 @@ namespace
         if ((rc = ctx->allocate<double>(size_t(n) * size_t(ctx->dev.num_instruments), &A.ptau, false, &own))) return rc;
         if ((rc = ctx->allocate<int32_t>(size_t(n) * size_t(ctx->dev.num_instruments), &A.ell, true, &own))) return rc;
         if ((rc = ctx->allocate<int32_t>(size_t(n) * size_t(ctx->dev.num_instruments), &A.nstat, true, &own))) return rc;
+        if ((rc = ctx->allocate<int32_t>(size_t(n) * size_t(ctx->dev.num_instruments), &A.statNext, false, &own))) return rc;
         if (ctx->dev.rf_store && (rc = ctx->allocate<int32_t>(n, &A.rfell, true, &own))) return rc;
         if (ctx->dev.any_stats)
         {
             size_t entries = size_t(ctx->dev.num_instruments) * PMC_STAT_CAP * size_t(n);
             if ((rc = ctx->allocate<int32_t>(entries, &A.statBin, false, &own))) return rc;
             if ((rc = ctx->allocate<double>(entries, &A.statW, false, &own))) return rc;
+            // continuation blocks of the lists (pmc_device.h DevScene::stat_pool_*): by default one block per four slots -- or,
+            // for a ski file that asks for many scattering events per history (minScattEvents), what such histories need in
+            // every slot at once; environment PMC_STAT_POOL_BLOCKS sets the number
+            DevScene& D = ctx->dev;
+            const int minEvents = D.min_scatt_events;
+            int64_t blocks = minEvents > 16 ? n * int64_t((minEvents + 2 * PMC_STAT_CAP - 1) / PMC_STAT_CAP) : n / 4;
+            blocks = std::max<int64_t>(blocks, 1024) * D.num_instruments;
+            if (const char* env = getenv("PMC_STAT_POOL_BLOCKS")) blocks = std::max<int64_t>(PMC_MAX_GROUPS, atoll(env));
+            blocks = std::min<int64_t>(blocks, int64_t(1) << 30);
+            if ((rc = ctx->allocate<int32_t>(size_t(blocks) * PMC_STAT_CAP, &D.stat_pool_bin, false, &own))) return rc;
+            if ((rc = ctx->allocate<double>(size_t(blocks) * PMC_STAT_CAP, &D.stat_pool_w, false, &own))) return rc;
+            if ((rc = ctx->allocate<int32_t>(size_t(blocks), &D.stat_pool_next, false, &own))) return rc;
+            if ((rc = ctx->allocate<int32_t>(size_t(blocks), &D.stat_pool_free, false, &own))) return rc;
+            if ((rc = ctx->allocate<int32_t>(size_t(blocks), &ctx->statPoolIota, false, &own))) return rc;
+            std::vector<int32_t> iota(static_cast<size_t>(blocks));
+            for (size_t i = 0; i < iota.size(); ++i) iota[i] = (int32_t)i;
+            if (hipMemcpy(ctx->statPoolIota, iota.data(), iota.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+                return fail(PMC_ERR_DEVICE, "hipMemcpy failed");
+            ctx->statPoolBlocks = blocks;
         }
         TaskArrays& K = ctx->dev.tasks;
         std::memset(&K, 0, sizeof(K));
@@ -501,7 +524,7 @@ void pmc_destroy(pmc_ctx* ctx)
         if (e) hipEventDestroy(e);
     for (int g = 0; g < PMC_MAX_GROUPS; ++g)
     {
-        for (hipEvent_t e : {ctx->evA[g], ctx->evB[g], ctx->evC[g], ctx->evJoin[g]})
+        for (hipEvent_t e : {ctx->evA[g], ctx->evB[g], ctx->evC[g], ctx->evJoin[g], ctx->evProp[g]})
             if (e) hipEventDestroy(e);
         if (g > 0 && ctx->groupStream[g]) hipStreamDestroy(ctx->groupStream[g]);
         if (ctx->peelStream[g]) hipStreamDestroy(ctx->peelStream[g]);
@@ -564,7 +587,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     for (hipEvent_t* ev : {&ctx->evStart, &ctx->evStop})
         if (hipEventCreate(ev) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipEventCreate failed"));
     for (int g = 0; g < PMC_MAX_GROUPS; ++g)
-        for (hipEvent_t* ev : {&ctx->evA[g], &ctx->evB[g], &ctx->evC[g], &ctx->evJoin[g]})
+        for (hipEvent_t* ev : {&ctx->evA[g], &ctx->evB[g], &ctx->evC[g], &ctx->evJoin[g], &ctx->evProp[g]})
             if (hipEventCreate(ev) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipEventCreate failed"));
     if (const char* env = getenv("PMC_NUM_GROUPS")) ctx->numGroups = std::min(PMC_MAX_GROUPS, std::max(1, atoi(env)));
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), 16 * sizeof(unsigned long long)) != hipSuccess)
@@ -986,7 +1009,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     }
     hipStream_t st = ctx->stream;
     unsigned long long* ctr = D.counters;
-    float walkMs = 0, transMs = 0, peelMs = 0;
+    float walkMs = 0, transMs = 0, peelMs = 0, propMs = 0;
     const bool serialWalks = getenv("PMC_SERIAL_WALKS") != nullptr;  // tuning aid: peel-off and propagation kernels one after the other
     const bool genDump = getenv("PMC_GEN_DUMP") != nullptr;  // tuning aid: live slots and kernel times of every generation
     int generations = 0;
@@ -1070,6 +1093,29 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         HIP_TRY(pmcLaunchRfReduce(ctx->slot, keys, vals, n, rfBuckets, sg));
         return PMC_OK;
     };
+    // ---- statistics: every slot group starts with its share of the pool of list blocks, all of them free
+    if (D.any_stats && ctx->statPoolBlocks)
+    {
+        const int64_t per = ctx->statPoolBlocks / G;
+        unsigned long long freeCount[PMC_MAX_GROUPS] = {0, 0, 0, 0};
+        bool changed = false;
+        for (int g = 0; g < PMC_MAX_GROUPS; ++g)
+        {
+            const int32_t firstBlock = g < G ? int32_t(g * per) : 0, count = g < G ? int32_t(per) : 0;
+            changed = changed || D.stat_pool_first[g] != firstBlock || D.stat_pool_count[g] != count;
+            D.stat_pool_first[g] = firstBlock;
+            D.stat_pool_count[g] = count;
+            freeCount[g] = (unsigned long long)count;
+        }
+        if (changed)
+        {
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(pmcUploadScene(ctx->slot, &D, st));
+        }
+        HIP_TRY(hipMemcpyAsync(D.stat_pool_free, ctx->statPoolIota, size_t(ctx->statPoolBlocks) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctr + PMC_CTR_STATFREE(0), freeCount, sizeof(freeCount), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));  // (freeCount lives on this frame)
+    }
     HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_HISTORY, 0, sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(ctr + 32, 0, 4 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(0, 0), 0, 16 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
@@ -1099,7 +1145,9 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                         HIP_TRY(pmcLaunchPeel(ctx->slot, ctx->wide, base[g], size[g], PMC_CTR_TASK(g, 1 + i), i, ctx->peelGrid, ctx->walkLds, sp));
                 HIP_TRY(hipEventRecord(ctx->evJoin[g], sp));
                 RfLogArgs log = {ctx->rfKeys[g][0], ctx->rfVals[g][0], rfLogged ? ctx->rfCap[g] : 0ull, PMC_CTR_RFLOG(g), rfPadKey};
+                if (serialWalks) HIP_TRY(hipEventRecord(ctx->evProp[g], sg));  // (in series: the propagation kernel starts where the peel-off kernels end)
                 HIP_TRY(pmcLaunchProp(ctx->slot, ctx->wide, D.rf_store, base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->walkLds, &log, sg));
+                if (!serialWalks) HIP_TRY(hipEventRecord(ctx->evProp[g], sg));
                 HIP_TRY(hipStreamWaitEvent(sg, ctx->evJoin[g], 0));
             }
             else
@@ -1150,10 +1198,16 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 HIP_TRY(hipEventElapsedTime(&ms, ctx->evA[g], ctx->evB[g]));
                 walkMs += ms;
                 walkOfGen = ms;
-                if (serialWalks && D.grid_kind == PMC_GRID_OCTREE)
+                if (D.grid_kind == PMC_GRID_OCTREE)
                 {
+                    // the two kernel kinds of the generation: side by side on two streams (each span starts at evA), or in series
                     HIP_TRY(hipEventElapsedTime(&ms, ctx->evA[g], ctx->evJoin[g]));
                     peelMs += ms;
+                    if (serialWalks)
+                        HIP_TRY(hipEventElapsedTime(&ms, ctx->evProp[g], ctx->evB[g]));
+                    else
+                        HIP_TRY(hipEventElapsedTime(&ms, ctx->evA[g], ctx->evProp[g]));
+                    propMs += ms;
                 }
             }
             HIP_TRY(hipEventElapsedTime(&ms, ctx->evB[g], ctx->evC[g]));
@@ -1188,8 +1242,10 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     HIP_TRY(hipEventElapsedTime(&ctx->totalMs, ctx->evStart, ctx->evStop));
     ctx->walkMs = walkMs;
     ctx->transitionMs = transMs;
+    ctx->peelMs = peelMs;
+    ctx->propMs = propMs;
     if (serialWalks && getenv("PMC_TIMING_DUMP"))
-        fprintf(stderr, "PMC_TIMING peel %.2f ms prop %.2f ms transition+launch %.2f ms segment %.2f ms\n", peelMs, walkMs - peelMs, transMs, ctx->totalMs);
+        fprintf(stderr, "PMC_TIMING peel %.2f ms prop %.2f ms transition+launch %.2f ms segment %.2f ms\n", peelMs, propMs, transMs, ctx->totalMs);
     ctx->generations = generations;
     ctx->timed = true;
     // a history with more distinct pixels than the statistics list holds: the statistics arrays are wrong -- say so
@@ -1201,9 +1257,10 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         {
             const unsigned long long fresh = overflows - ctx->overflowsSeen;
             ctx->overflowsSeen = overflows;
-            return fail(PMC_ERR_OVERFLOW, std::to_string(fresh) + " photon histories contributed to more than " + std::to_string(PMC_STAT_CAP)
-                                              + " distinct pixels of an instrument: the statistics arrays of this segment are incomplete "
-                                                "(FluxRecorder.cpp:962-1014 is unbounded); run without recordStatistics");
+            return fail(PMC_ERR_OVERFLOW, std::to_string(fresh) + " photon histories lost contributions to the statistics arrays: the pool of "
+                                              + std::to_string(ctx->statPoolBlocks) + " list blocks (" + std::to_string(PMC_STAT_CAP)
+                                              + " distinct pixels each) ran out; the statistics arrays of this segment are incomplete.  Raise "
+                                                "PMC_STAT_POOL_BLOCKS, or lower PMC_NUM_SLOTS (fewer histories in flight)");
         }
     }
     return PMC_OK;
@@ -1233,6 +1290,27 @@ int pmc_last_timing(pmc_ctx* ctx, float* total_ms, float* walk_ms, float* transi
     if (walk_ms) *walk_ms = ctx->walkMs;
     if (transition_ms) *transition_ms = ctx->transitionMs;
     if (generations) *generations = ctx->generations;
+    return PMC_OK;
+}
+
+int pmc_last_walk_timing(pmc_ctx* ctx, float* peel_ms, float* prop_ms)
+{
+    if (!ctx) return fail(PMC_ERR_INVALID, "null argument");
+    if (!ctx->timed) return fail(PMC_ERR_INVALID, "no segment has been run yet");
+    if (peel_ms) *peel_ms = ctx->peelMs;
+    if (prop_ms) *prop_ms = ctx->propMs;
+    return PMC_OK;
+}
+
+int pmc_walk_work(pmc_ctx* ctx, pmc_walk_work_values* out)
+{
+    if (!ctx || !out) return fail(PMC_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long host[6];
+    HIP_TRY(hipMemcpy(host, ctx->dev.counters + PMC_CTR_WALKWORK, sizeof(host), hipMemcpyDeviceToHost));
+    out->peel_wave_steps = host[0], out->peel_lane_steps = host[1], out->peel_rounds = host[2];
+    out->prop_wave_steps = host[3], out->prop_lane_steps = host[4], out->prop_rounds = host[5];
     return PMC_OK;
 }
 
@@ -1460,6 +1538,18 @@ int pmc_comm_init_rank(int32_t device, int32_t num_ranks, int32_t rank, const vo
     std::memcpy(&id, unique_id, sizeof(id));
     ncclResult_t r = ncclCommInitRank(reinterpret_cast<ncclComm_t*>(comm), num_ranks, id, rank);
     return r == ncclSuccess ? PMC_OK : ncclFail(r, "ncclCommInitRank");
+}
+
+int pmc_comm_size(void* comm, int32_t* num_ranks, int32_t* rank)
+{
+    if (!comm) return fail(PMC_ERR_INVALID, "pmc_comm_size: null argument");
+    int n = 0, me = 0;
+    ncclResult_t r = ncclCommCount(reinterpret_cast<ncclComm_t>(comm), &n);
+    if (r == ncclSuccess) r = ncclCommUserRank(reinterpret_cast<ncclComm_t>(comm), &me);
+    if (r != ncclSuccess) return ncclFail(r, "ncclCommCount");
+    if (num_ranks) *num_ranks = n;
+    if (rank) *rank = me;
+    return PMC_OK;
 }
 
 void pmc_comm_destroy(void* comm)

@@ -22,8 +22,11 @@
                                 // the per-instrument slot arrays are sized by the scene's own instrument count)
 #define PMC_MAX_CONTEXTS 8  // scene slots in constant memory (live contexts per process and device)
 #define PMC_MAX_LEVEL 12
-#define PMC_STAT_CAP 48     // per-history list capacity per instrument: DISTINCT pixels a history contributes to (FluxRecorder
-                            // statistics); a multiple of 4
+#define PMC_STAT_CAP 48     // entries of a slot's own contribution list per instrument: DISTINCT pixels a history contributes to
+                            // (FluxRecorder statistics); a multiple of 4.  A history with more distinct pixels continues its list in
+                            // chained blocks of PMC_STAT_CAP entries from the slot group's pool (DevScene::stat_pool_*): the
+                            // reference's list is unbounded (FluxRecorder.hpp:327-338)
+#define PMC_STAT_POOL_EXHAUSTED 0x40000000  // flag in SlotArrays::nstat: a contribution was lost because the pool had no block left
 
 // link word (uint32): bits 0-3 size exponent e of the target box (its edge spans 2^e finest cells), bits 4-29 index,
 // bits 30-31 kind: 0 leaf cell (device index), PMC_LINK_NODE internal node (NodeRec index), PMC_LINK_OCTET internal node
@@ -113,7 +116,8 @@ struct SlotArrays
     int32_t* pscatt;                        // numScatt of the cycle's peel-off packets (0: emission)
     int32_t* cellhint;                      // octree leaf that contains the position, or -1
     int32_t* ell;                           // [num_instruments][num_slots] wavelength bin per instrument
-    int32_t* nstat;                         // [num_instruments][num_slots] length of the contribution list
+    int32_t* nstat;                         // [num_instruments][num_slots] length of the contribution list (own entries + chained blocks)
+    int32_t* statNext;                      // [num_instruments][num_slots] first chained block of the list, -1: none
     int32_t* rfell;                         // wavelength bin in the radiation field grid, -1 outside (only if rf_store)
     // walk results
     double* ptau;                           // [num_instruments][num_slots] optical depth towards that observer (inf: the
@@ -257,6 +261,17 @@ struct DevScene
     // at the end of every segment (statMergeKernel)
     double* stat_acc;
     int64_t stat_acc_records;
+    // continuation blocks of the per-history contribution lists (instruments with statistics): block b holds PMC_STAT_CAP
+    // entries (stat_pool_bin / stat_pool_w [b * PMC_STAT_CAP + q]) and the id of the block that follows it (stat_pool_next[b],
+    // -1: none).  Every slot group owns the ids [stat_pool_first[g], stat_pool_first[g] + stat_pool_count[g]) and keeps its free
+    // ids as a stack in stat_pool_free over the same index range, filled up to counters[PMC_CTR_STATFREE(g)]: the transition
+    // kernel of a group only takes blocks, its launch kernel only returns them, and the two never overlap (one stream).
+    int32_t* stat_pool_bin;
+    double*  stat_pool_w;
+    int32_t* stat_pool_next;
+    int32_t* stat_pool_free;
+    int32_t  stat_pool_first[4];
+    int32_t  stat_pool_count[4];
     unsigned long long* counters;  // [PMC_NUM_COUNTERS]: [0..6] pmc_counter_values, [8] next history offset,
                                    // [16..21] walk work, [32 + 4 g ..] work counters of slot group g, [120 + g] history bases,
                                    // [128 + 16 g ..] task cursors (PMC_CTR_*), [192..239] section timers of profiling builds
@@ -299,6 +314,8 @@ struct RfLogArgs
 // per slot group g: offset of the first history the group's ended slots take up this generation (endedScanKernel)
 #define PMC_CTR_HBASE(g) (120 + (g))
 #define PMC_MAX_GROUPS 4
+// per slot group g: free blocks of the group's share of the statistics pool (DevScene::stat_pool_free)
+#define PMC_CTR_STATFREE(g) (48 + (g))
 #define PMC_TRANSITION_ALIGN 1024  // slot groups start at multiples of the transition kernel's workgroup size
 
 #endif

@@ -51,6 +51,7 @@
 #include <float.h>
 #include <math.h>
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 
 #ifndef PMC_WALK_REFILL
@@ -115,6 +116,8 @@
     #define PMC_TRANSITION_BLOCK 256  // lanes per workgroup of the transition kernel: 256 measured 4 % faster than 512
                                       // (profiles/README.md); small enough to share a CU with the walk kernel
 #endif
+static_assert(PMC_TRANSITION_BLOCK <= 256 && PMC_TRANSITION_BLOCK % 64 == 0,
+              "the per-wave slot lists of the transition and launch kernels are laid out for at most four waves per workgroup");
 #ifndef PMC_TASK_CHUNK
     #define PMC_TASK_CHUNK 128  // slots a wave takes from the global cursor at a time
 #endif
@@ -221,9 +224,18 @@ static size_t pmcPeelQueueBytes()
 
 extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
 {
+    // (contexts are created concurrently by one host thread per device; the attribute is per device, so every pmc_create
+    // sets it on its own current device)
+    static std::mutex lock;
+    std::lock_guard<std::mutex> guard(lock);
     static size_t walkMax = 0, transitionMax = 0;
     walkMax = std::max(walkMax, walkLds);
     transitionMax = std::max(transitionMax, transitionLds);
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfReduceKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(sizeof(double) << PMC_RF_BUCKET_BITS));
+        if (e != hipSuccess) return e;
+    }
     const struct
     {
         const void* kernel;
@@ -346,14 +358,7 @@ extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBas
 // radiation field: the sorted (or, for a table of one partition, unsorted) log of a generation added to the table
 extern "C" hipError_t pmcLaunchRfReduce(int slot, const uint32_t* keys, const double* vals, unsigned long long n, int numBuckets, hipStream_t stream)
 {
-    static bool configured = false;
-    const size_t lds = sizeof(double) << PMC_RF_BUCKET_BITS;
-    if (!configured)
-    {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfReduceKernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    const size_t lds = sizeof(double) << PMC_RF_BUCKET_BITS;  // (the limit is raised per device in pmcConfigureKernels)
     const unsigned long long blocks = (n + PMC_RF_REDUCE_SPAN - 1) / PMC_RF_REDUCE_SPAN;
     hipLaunchKernelGGL(rfReduceKernel, dim3((unsigned)blocks), dim3(256), lds, stream, slot, keys, vals, n, (uint32_t)numBuckets);
     return hipGetLastError();

@@ -18,12 +18,18 @@ _LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 SYMBOLS = ["pmc_abi_version", "pmc_last_error", "pmc_frame_layout_of", "pmc_create", "pmc_destroy", "pmc_bind_frames",
            "pmc_clear_frames", "pmc_run_primary", "pmc_sync", "pmc_download", "pmc_frames_device", "pmc_frames_size",
            "pmc_last_kernel_ms", "pmc_counters", "pmc_reset_counters", "pmc_trace_ray", "pmc_set_launch",
-           "pmc_set_num_slots", "pmc_last_timing", "pmc_radiation_field_size", "pmc_radiation_field_device",
+           "pmc_set_num_slots", "pmc_last_timing", "pmc_last_walk_timing", "pmc_walk_work", "pmc_radiation_field_size", "pmc_radiation_field_device",
            "pmc_download_radiation_field", "pmc_clear_radiation_field", "pmc_bind_radiation_field", "pmc_sampler_create",
            "pmc_sampler_density", "pmc_sampler_destroy", "pmc_history_range", "pmc_comm_init_all", "pmc_comm_unique_id",
-           "pmc_comm_init_rank", "pmc_comm_destroy", "pmc_reduce_frames", "pmc_allreduce_radiation_field"]
+           "pmc_comm_init_rank", "pmc_comm_size", "pmc_comm_destroy", "pmc_reduce_frames", "pmc_allreduce_radiation_field"]
 
 _lib = None
+
+
+class WalkWork(C.Structure):
+    """pmc_walk_work_values (include/pmc.h)"""
+    _fields_ = [(n, C.c_uint64) for n in ("peel_wave_steps", "peel_lane_steps", "peel_rounds", "prop_wave_steps",
+                                          "prop_lane_steps", "prop_rounds")]
 
 
 def lib():
@@ -57,6 +63,8 @@ def lib():
         L.pmc_set_num_slots.argtypes = [C.c_void_p, C.c_int64]
         L.pmc_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                       C.POINTER(C.c_int32)]
+        L.pmc_last_walk_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.pmc_walk_work.argtypes = [C.c_void_p, C.POINTER(WalkWork)]
         L.pmc_radiation_field_size.restype = C.c_int64
         L.pmc_radiation_field_size.argtypes = [C.c_void_p]
         L.pmc_radiation_field_device.restype = C.c_void_p
@@ -69,6 +77,7 @@ def lib():
         L.pmc_comm_init_all.argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]
         L.pmc_comm_unique_id.argtypes = [C.c_void_p]
         L.pmc_comm_init_rank.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.pmc_comm_size.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.pmc_comm_destroy.restype = None
         L.pmc_comm_destroy.argtypes = [C.c_void_p]
         L.pmc_reduce_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
@@ -117,6 +126,12 @@ class Communicator:
         out = C.c_void_p()
         _check(lib().pmc_comm_init_rank(device, num_ranks, rank, C.c_char_p(unique_id), C.byref(out)))
         return cls([out])
+
+    def size(self, index=0):
+        """(ranks of the communicator, rank of handle `index` in it) as RCCL reports them"""
+        n, me = C.c_int32(0), C.c_int32(0)
+        _check(lib().pmc_comm_size(self.handles[index], C.byref(n), C.byref(me)))
+        return int(n.value), int(me.value)
 
     def close(self):
         for h in self.handles:
@@ -183,6 +198,18 @@ class Engine:
         _check(lib().pmc_last_timing(self._h, C.byref(t), C.byref(w), C.byref(x), C.byref(g)))
         return {"total_ms": float(t.value), "walk_ms": float(w.value), "transition_ms": float(x.value),
                 "generations": int(g.value)}
+
+    def last_walk_timing(self):
+        """octree: HIP-event spans of the peel-off kernels and of the propagation kernel of the last segment (they overlap)"""
+        a, b = C.c_float(0), C.c_float(0)
+        _check(lib().pmc_last_walk_timing(self._h, C.byref(a), C.byref(b)))
+        return {"peel_ms": float(a.value), "prop_ms": float(b.value)}
+
+    def walk_work(self):
+        """counted wave-steps, lane-steps and bookkeeping rounds of the octree walk kernels since create / reset"""
+        w = WalkWork()
+        _check(lib().pmc_walk_work(self._h, C.byref(w)))
+        return {n: int(getattr(w, n)) for n, _ in w._fields_}
 
     def reduce_frames(self, comm_handle, root=0):
         """end of a segment on several devices: ONE ncclReduce (f64, sum) of the detector arrays onto `root`

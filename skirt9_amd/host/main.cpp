@@ -14,9 +14,11 @@
 #include "../../include/pmc.h"
 #include "../../include/skirt_host.h"
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -40,10 +42,22 @@ int main(int argc, char** argv)
             forceComm = true;
         else if (!strcmp(argv[i], "-g") && i + 1 < argc)
         {
-            for (const char* p = argv[++i]; *p;)
+            // a comma-separated list of distinct, non-negative device indices; anything else is a usage error
+            const char* p = argv[++i];
+            bool ok = *p != 0;
+            while (ok && *p)
             {
-                devices.push_back((int32_t)strtol(p, const_cast<char**>(&p), 10));
-                if (*p == ',') ++p;
+                char* end = nullptr;
+                const long v = strtol(p, &end, 10);
+                ok = end != p && v >= 0 && v < 1024 && (*end == ',' || *end == 0) && !(*end == ',' && end[1] == 0);
+                for (int32_t d : devices) ok = ok && d != (int32_t)v;
+                if (ok) devices.push_back((int32_t)v);
+                p = *end == ',' ? end + 1 : end;
+            }
+            if (!ok)
+            {
+                fprintf(stderr, "skirt_mi355x: -g takes a comma-separated list of distinct device indices, e.g. -g 0,1,2,3\n");
+                return 2;
             }
         }
         else if (!strcmp(argv[i], "-n") && i + 1 < argc)
@@ -107,13 +121,34 @@ int main(int argc, char** argv)
     std::vector<pmc_counter_values> counts(G);
     std::vector<double> frames(skh_frame_size(sim));
     std::vector<double> rf(skh_radiation_field_size(sim));
+    // Every device thread either enters the collectives or none does: a thread whose context or segment failed would
+    // otherwise leave the others waiting in ncclReduce for ever.  The threads meet once after their segments; if any of
+    // them failed, all skip the collectives.
+    std::mutex meetLock;
+    std::condition_variable meetCv;
+    int arrived = 0, failures = 0;
+    auto meet = [&](bool ok) {
+        std::unique_lock<std::mutex> lock(meetLock);
+        arrived += 1;
+        if (!ok) failures += 1;
+        if (arrived == G)
+            meetCv.notify_all();
+        else
+            meetCv.wait(lock, [&] { return arrived == G; });
+        return failures == 0;
+    };
     auto work = [&](int g) {
         auto failed = [&]() { errors[g] = pmc_last_error(); };
-        if (pmc_create(skh_scene(sim), devices[g], &ctxs[g]) != PMC_OK) return failed();
-        uint64_t first = 0, count = 0;
-        pmc_history_range(n, g, G, &first, &count);
-        if (pmc_run_primary(ctxs[g], first, count, (uint64_t)skh_seed(sim)) != PMC_OK) return failed();
-        pmc_counters(ctxs[g], &counts[g]);
+        bool ok = pmc_create(skh_scene(sim), devices[g], &ctxs[g]) == PMC_OK;
+        if (ok)
+        {
+            uint64_t first = 0, count = 0;
+            pmc_history_range(n, g, G, &first, &count);
+            ok = pmc_run_primary(ctxs[g], first, count, (uint64_t)skh_seed(sim)) == PMC_OK;
+        }
+        if (!ok) failed();
+        if (ok) pmc_counters(ctxs[g], &counts[g]);
+        if (!meet(ok) || !ok) return;
         if (useComm && pmc_reduce_frames(ctxs[g], comms[g], 0) != PMC_OK) return failed();
         if (useComm && !rf.empty() && pmc_allreduce_radiation_field(ctxs[g], comms[g]) != PMC_OK) return failed();
         if (g == 0)

@@ -31,8 +31,8 @@ def test_every_declared_symbol_is_exported(libpmc):
 
 
 def test_history_range_is_the_library_function(libpmc):
-    """skirt9_amd.distributed.history_range, the CLI driver and the bench share pmc_history_range (pure host code)"""
-    from skirt9_amd.distributed import history_range
+    """skirt9_amd.engine.history_range, the CLI driver and the bench share pmc_history_range (pure host code)"""
+    from skirt9_amd.engine import history_range
     for n, world in ((10 ** 9, 8), (7, 3), (0, 4), (2 ** 63 + 12345, 8)):
         cuts = [history_range(n, r, world) for r in range(world)]
         assert cuts[0][0] == 0 and sum(c for _, c in cuts) == n

@@ -74,26 +74,57 @@ def test_cli_driver_with_the_collective(tmp_path):
             assert x.shape == y.shape and np.allclose(x, y, rtol=1e-5, atol=1e-7 * np.abs(x).max())
 
 
-def test_statistics_overflow_is_an_error(tmp_path):
-    """FluxRecorder::recordContributions (FluxRecorder.cpp:962-1014) keeps any number of contributions per history; the
-    engine's list holds 48 distinct pixels per instrument.  A scene that exceeds it (120 scattering events per history)
-    must make pmc_run_primary FAIL instead of returning statistics computed from a truncated list; the same scene with
-    few events must pass (many contributions to the same pixel share one entry)"""
-    from skirt9_amd.engine import Engine
-    from skirt9_amd.host import Simulation
+def _many_events(tmp_path, events):
     text = open(ski("cfg2small.ski")).read()
     assert 'minScattEvents="0"' in text
-    many = tmp_path / "many.ski"
-    many.write_text(text.replace('minScattEvents="0"', 'minScattEvents="120"'))
-    sim = Simulation(str(many), num_packets=500).setup()
+    path = tmp_path / f"events{events}.ski"
+    path.write_text(text.replace('minScattEvents="0"', f'minScattEvents="{events}"'))
+    return str(path)
+
+
+def test_statistics_lists_are_unbounded(tmp_path):
+    """FluxRecorder::recordContributions (FluxRecorder.cpp:962-1014, FluxRecorder.hpp:327-338) keeps any number of
+    contributions per history.  A slot's own list holds 48 distinct pixels per instrument; a history with more continues
+    in chained blocks from the slot group's pool.  120 scattering events per history (every history leaves its own list):
+    the statistics arrays must agree with the oracle's, which keeps a std::vector per history."""
+    import oracle_lib as O
+    from skirt9_amd.engine import Engine
+    from skirt9_amd.host import Simulation
+    from test_gpu_parity import _compare_frames
+    n = 2000
+    sim = Simulation(_many_events(tmp_path, 120), num_packets=n).setup()
     eng = Engine(sim.scene, 0)
-    with pytest.raises(RuntimeError, match="distinct pixels"):
+    eng.run_primary(0, n, 1)
+    gpu = eng.download()
+    c = eng.counters()
+    eng.close()
+    assert c["stat_overflows"] == 0 and c["scatterings"] >= 100 * n
+    ref, counters = O.run_primary(sim, 0, n, O.RNG_PHILOX, seed=1)
+    _compare_frames(sim, gpu, ref, n)
+    lay = sim.layout(0)
+    npix = lay.npix * lay.num_lambda
+    for k in range(5):
+        a = gpu[lay.wifu_offset + k * npix:lay.wifu_offset + (k + 1) * npix]
+        b = ref[lay.wifu_offset + k * npix:lay.wifu_offset + (k + 1) * npix]
+        assert abs(a.sum() - b.sum()) <= 1e-9 * np.abs(b).sum()
+    # sum of w^0 over the pixels = number of (history, distinct pixel) pairs: beyond 48 per history on average
+    assert ref[lay.wifu_offset:lay.wifu_offset + npix].sum() > 50 * n
+    assert gpu[lay.wifu_offset:lay.wifu_offset + npix].sum() == ref[lay.wifu_offset:lay.wifu_offset + npix].sum()
+
+
+def test_statistics_pool_exhaustion_is_an_error(tmp_path, monkeypatch):
+    """the pool of list blocks is finite (device memory): a segment that runs out of blocks must FAIL instead of returning
+    statistics computed from truncated lists; the next segment starts with a full pool again"""
+    from skirt9_amd.engine import Engine
+    from skirt9_amd.host import Simulation
+    monkeypatch.setenv("PMC_STAT_POOL_BLOCKS", "16")
+    sim = Simulation(_many_events(tmp_path, 120), num_packets=500).setup()
+    eng = Engine(sim.scene, 0)
+    with pytest.raises(RuntimeError, match="PMC_STAT_POOL_BLOCKS"):
         eng.run_primary(0, 500, 1)
     assert eng.counters()["stat_overflows"] > 0
     eng.close()
-    few = tmp_path / "few.ski"
-    few.write_text(text.replace('minScattEvents="0"', 'minScattEvents="20"'))
-    sim = Simulation(str(few), num_packets=500).setup()
+    sim = Simulation(_many_events(tmp_path, 20), num_packets=500).setup()
     eng = Engine(sim.scene, 0)
     eng.run_primary(0, 500, 1)
     assert eng.counters()["stat_overflows"] == 0

@@ -1,6 +1,7 @@
 """The N>1 path on CPU: two processes (gloo), static history-range split, one reduce of the detector arrays onto
 rank 0.  The photon loop stand-in here is the CPU oracle with the engine's per-history streams (the real engine
-needs a GPU); what is under test is the sharding rule and the reduce of skirt9_amd.distributed."""
+needs a GPU); what is under test is the sharding rule (pmc_history_range)
+and that the detector arrays and the radiation field of the shards add up to those of the undivided segment."""
 import os
 import sys
 
@@ -17,7 +18,7 @@ def _worker(rank, world, port, n, outfile):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    from skirt9_amd.distributed import history_range, reduce_frames
+    from skirt9_amd.engine import history_range
     from skirt9_amd.host import Simulation
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -26,7 +27,7 @@ def _worker(rank, world, port, n, outfile):
     first, count = history_range(n, rank, world)
     frames, _ = O.run_primary(sim, first, count, O.RNG_PHILOX, seed=11)
     t = torch.from_numpy(frames)
-    reduce_frames(t, dst=0)
+    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)  # (on the GPU: pmc_reduce_frames, one ncclReduce onto the root)
     if rank == 0:
         np.save(outfile, t.numpy())
     dist.barrier()
@@ -34,7 +35,7 @@ def _worker(rank, world, port, n, outfile):
 
 
 def test_history_range_partition():
-    from skirt9_amd.distributed import history_range
+    from skirt9_amd.engine import history_range
     for n in (0, 1, 7, 1000, 10 ** 9 + 7):
         for world in (1, 2, 3, 8):
             pieces = [history_range(n, r, world) for r in range(world)]
@@ -63,7 +64,7 @@ def _rf_worker(rank, world, port, n, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    from skirt9_amd.distributed import allreduce_radiation_field, history_range
+    from skirt9_amd.engine import history_range
     from skirt9_amd.host import Simulation
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -72,7 +73,7 @@ def _rf_worker(rank, world, port, n, outdir):
     first, count = history_range(n, rank, world)
     _, rf, _ = O.run_primary_rf(sim, first, count, O.RNG_PHILOX, seed=3)
     t = torch.from_numpy(rf)
-    allreduce_radiation_field(t)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)  # (on the GPU: pmc_allreduce_radiation_field)
     np.save(os.path.join(outdir, f"rf{rank}.npy"), t.numpy())  # every rank must hold the whole field (sumToAll)
     dist.barrier()
     dist.destroy_process_group()

@@ -33,3 +33,5 @@ done
 find $O -name "*kernel_trace.csv" -size +20M -delete
 find $O -name "*pc_sampling*.csv" -size +40M -exec sh -c 'head -c 40000000 "$1" > "$1.head"; rm "$1"' _ {} \;
 du -sh $O
+cd $R
+timeout 600 python -m pytest tests -m gpu -x -q > $O/gputests.txt 2>&1; echo "gpu tests rc=$?"; tail -3 $O/gputests.txt

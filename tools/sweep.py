@@ -48,10 +48,25 @@ def main():
             eng.run_primary((rep + 1) * P, P, sim.seed)
             eng.sync()
             t = eng.last_timing()
+            try:
+                t["kernels"] = eng.last_walk_timing()
+            except Exception:  # noqa: BLE001
+                t["kernels"] = None
             if best is None or t["total_ms"] < best["total_ms"]:
                 best = t
         print(f"{v:60s} pkt/s {P / best['total_ms'] * 1e3:.3e} seg {best['total_ms']:.1f} walk {best['walk_ms']:.1f} "
               f"trans {best['transition_ms']:.1f} gen {best['generations']}  sum {frames.sum().item():.9e}", flush=True)
+        try:
+            # octree: the two walk kernels apart (spans overlap unless PMC_SERIAL_WALKS), lane-steps counted over both timed segments
+            w, k = eng.walk_work(), best["kernels"]
+            if w["prop_wave_steps"]:
+                print(f"    peel {k['peel_ms']:.1f} ms, {w['peel_lane_steps'] / 2 / P:.1f} lane-steps/packet, "
+                      f"{w['peel_lane_steps'] / 2 / k['peel_ms'] / 1e8:.3f}e11 lane-steps/s, lanes {w['peel_lane_steps'] / 0.64 / w['peel_wave_steps']:.1f} %;  "
+                      f"prop {k['prop_ms']:.1f} ms, {w['prop_lane_steps'] / 2 / P:.1f} lane-steps/packet, "
+                      f"{w['prop_lane_steps'] / 2 / k['prop_ms'] / 1e8:.3f}e11 lane-steps/s, lanes {w['prop_lane_steps'] / 0.64 / w['prop_wave_steps']:.1f} %",
+                      flush=True)
+        except Exception as exc:  # noqa: BLE001 - variants built before the ABI had these entries
+            print(f"    (no per-kernel figures: {exc})", flush=True)
         if os.environ.get("PMC_PROFILE_DUMP"):
             eng.counters()  # a profiling build prints its in-kernel timers to stderr
         eng.close()
