@@ -100,7 +100,7 @@ struct pmc_ctx
     double* frames{nullptr};
     int64_t frameSize{0};
     int64_t rfSize{0};  // doubles of the radiation field table (0: not stored)
-    size_t walkLds{0}, transitionLds{0};
+    size_t walkLds{0}, transitionLds{0}, launchLds{0};
     int block{256};
     int grid{0};          // workgroups of the generic walk kernel / the octree propagation kernel
     int peelGrid{0};      // workgroups of an octree peel-off kernel
@@ -134,10 +134,19 @@ struct pmc_ctx
         *out = static_cast<const T*>(d);
         return PMC_OK;
     }
+    // (planning pass of allocateSlots: the requests are only added up)
+    bool planning{false};
+    size_t plannedBytes{0};
+
     template<typename T> int allocate(size_t count, T** out, bool zero, std::vector<void*>* owner = nullptr)
     {
         *out = nullptr;
         if (!count) return PMC_OK;
+        if (planning)
+        {
+            plannedBytes += (count * sizeof(T) + 255) & ~size_t(255);
+            return PMC_OK;
+        }
         void* d = nullptr;
         hipError_t e = hipMalloc(&d, count * sizeof(T));
         if (e != hipSuccess) return hipFail(e, "hipMalloc");
@@ -419,22 +428,54 @@ namespace
         return PMC_OK;
     }
 
+    int allocateSlotArrays(pmc_ctx* ctx, int64_t n);
+
+    // the slot pool of n histories in flight: first added up and held against the free device memory (a clear message instead of
+    // a failed hipMalloc half-way), then allocated
     int allocateSlots(pmc_ctx* ctx, int64_t n)
     {
         hipSetDevice(ctx->device);
         for (void* p : ctx->slotAllocations) hipFree(p);
         ctx->slotAllocations.clear();
+        ctx->allocatedSlots = 0;
+        ctx->planning = true;
+        ctx->plannedBytes = 0;
+        int rc = allocateSlotArrays(ctx, n);
+        ctx->planning = false;
+        if (rc) return rc;
+        size_t freeBytes = 0, totalBytes = 0;
+        if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && ctx->plannedBytes > freeBytes)
+        {
+            char text[512];
+            snprintf(text, sizeof(text),
+                     "the state of %lld photon histories in flight needs %.2f GB of device memory (%.0f bytes per history), %.2f GB of %.2f GB are "
+                     "free: lower the number with pmc_set_num_slots or PMC_NUM_SLOTS",
+                     (long long)n, ctx->plannedBytes * 1e-9, double(ctx->plannedBytes) / double(n), freeBytes * 1e-9, totalBytes * 1e-9);
+            return fail(PMC_ERR_NOMEM, text);
+        }
+        rc = allocateSlotArrays(ctx, n);
+        if (rc)
+        {
+            for (void* p : ctx->slotAllocations) hipFree(p);
+            ctx->slotAllocations.clear();
+            ctx->allocatedSlots = 0;
+        }
+        return rc;
+    }
+
+    int allocateSlotArrays(pmc_ctx* ctx, int64_t n)
+    {
         SlotArrays& A = ctx->dev.slots;
         std::memset(&A, 0, sizeof(A));
         auto& own = ctx->slotAllocations;
         int rc;
         double** dbl[] = {&A.rx, &A.ry, &A.rz, &A.kx, &A.ky, &A.kz, &A.lambda, &A.W, &A.Lthreshold, &A.taupath, &A.tausample, &A.rngSpare, &A.sint,
-                          &A.nint};
+                          &A.nint, &A.dustExt, &A.dustSca, &A.dustAsym};
         for (double** d : dbl)
             if ((rc = ctx->allocate<double>(n, d, false, &own))) return rc;
         if ((rc = ctx->allocate<uint64_t>(n, &A.history, false, &own))) return rc;
         if ((rc = ctx->allocate<uint32_t>(n, &A.rngBlock, false, &own))) return rc;
-        int32_t** ints[] = {&A.dustIndex, &A.mode, &A.nscatt, &A.pscatt, &A.cellhint, &A.mint};
+        int32_t** ints[] = {&A.mode, &A.nscatt, &A.pscatt, &A.cellhint, &A.mint};
         for (int32_t** d : ints)
             if ((rc = ctx->allocate<int32_t>(n, d, true, &own))) return rc;
         if ((rc = ctx->allocate<double>(size_t(n) * size_t(ctx->dev.num_instruments), &A.ppW, false, &own))) return rc;
@@ -462,11 +503,14 @@ namespace
             if ((rc = ctx->allocate<int32_t>(size_t(blocks), &D.stat_pool_next, false, &own))) return rc;
             if ((rc = ctx->allocate<int32_t>(size_t(blocks), &D.stat_pool_free, false, &own))) return rc;
             if ((rc = ctx->allocate<int32_t>(size_t(blocks), &ctx->statPoolIota, false, &own))) return rc;
-            std::vector<int32_t> iota(static_cast<size_t>(blocks));
-            for (size_t i = 0; i < iota.size(); ++i) iota[i] = (int32_t)i;
-            if (hipMemcpy(ctx->statPoolIota, iota.data(), iota.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
-                return fail(PMC_ERR_DEVICE, "hipMemcpy failed");
-            ctx->statPoolBlocks = blocks;
+            if (!ctx->planning)
+            {
+                std::vector<int32_t> iota(static_cast<size_t>(blocks));
+                for (size_t i = 0; i < iota.size(); ++i) iota[i] = (int32_t)i;
+                if (hipMemcpy(ctx->statPoolIota, iota.data(), iota.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+                    return fail(PMC_ERR_DEVICE, "hipMemcpy failed");
+                ctx->statPoolBlocks = blocks;
+            }
         }
         TaskArrays& K = ctx->dev.tasks;
         std::memset(&K, 0, sizeof(K));
@@ -482,6 +526,7 @@ namespace
         if ((rc = ctx->allocate<uint32_t>(size_t(n) / 64 + 64, &K.endedCount, true, &own))) return rc;
         if ((rc = ctx->allocate<uint32_t>(nt, &K.bits, false, &own))) return rc;
     if (ctx->dev.grid_kind == PMC_GRID_OCTREE && (rc = ctx->allocate<uint64_t>(nt, &K.pidx, false, &own))) return rc;
+        if (ctx->planning) return PMC_OK;
         A.num_slots = n;
         ctx->allocatedSlots = n;
         ctx->sceneDirty = true;
@@ -758,11 +803,9 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     if ((rc = ctx->upload(med.sigma_ext, med.num_lambda, &D.sigma_ext))) return bail(rc);
     if ((rc = ctx->upload(med.sigma_sca, med.num_lambda, &D.sigma_sca))) return bail(rc);
     if ((rc = ctx->upload(med.asymmpar, med.num_lambda, &D.asymmpar))) return bail(rc);
-    D.dust_in_lds = med.num_lambda <= 2048;  // <= 64 KiB for the four tables
     int walkDoubles = D.lds_grid_len;
     int transDoubles = D.lds_grid_len;  // the grid tables come first in every kernel
-    D.lds_dust_off = transDoubles;
-    if (D.dust_in_lds) transDoubles += 4 * med.num_lambda;
+    int launchOnlyDoubles = 0;          // what only the launch kernel stages, behind the regions the two kernels share
 
     D.force_scattering = scene->options.force_scattering;
     D.min_weight_reduction = scene->options.min_weight_reduction;
@@ -774,7 +817,6 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     if (numSources > PMC_MAX_SOURCES) return bail(fail(PMC_ERR_UNSUPPORTED, "more than " + std::to_string(PMC_MAX_SOURCES) + " sources"));
     if (numSources > 1 && (!scene->sources || !scene->source_first)) return bail(fail(PMC_ERR_INVALID, "source tables missing"));
     D.num_sources = numSources;
-    D.lds_src_off = transDoubles;
     for (int si = 0; si < numSources; ++si)
     {
         const pmc_source& src = numSources > 1 ? scene->sources[si] : scene->source;
@@ -802,7 +844,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
             if (src.sersic_n < 2) return bail(fail(PMC_ERR_INVALID, "Sersic source without tables"));
             if ((rc = ctx->upload(src.sersic_s, src.sersic_n, &Q.sersic_s))) return bail(rc);
             if ((rc = ctx->upload(src.sersic_M, src.sersic_n, &Q.sersic_M))) return bail(rc);
-            if (numSources == 1) transDoubles += 2 * src.sersic_n;
+            if (numSources == 1) launchOnlyDoubles += 2 * src.sersic_n;
         }
         else if (src.kind != PMC_SOURCE_POINT && src.kind != PMC_SOURCE_UNIFORM_BOX && src.kind != PMC_SOURCE_EXP_DISK
                  && src.kind != PMC_SOURCE_PLUMMER)
@@ -898,12 +940,20 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     D.lds_sort_off = transDoubles;
     transDoubles += (64 + 2 * 1024 + 8) / 2;  // integer scratch: regrouping arrays and list-append counters
     D.lds_total_transition = transDoubles;
+    // launch kernel: Sersic tables, then the index borders of the dust mix (DustMix::_lambdav: the binary search of every new
+    // history's wavelength) if they fit in 64 KiB
+    D.lds_src_off = transDoubles;
+    D.lds_dust_off = transDoubles + launchOnlyDoubles;
+    D.dust_in_lds = med.num_lambda <= 8192;
+    if (D.dust_in_lds) launchOnlyDoubles += med.num_lambda;
+    D.lds_total_launch = transDoubles + launchOnlyDoubles;
     D.lds_total_walk = walkDoubles;
     ctx->walkLds = size_t(walkDoubles) * sizeof(double);
     ctx->transitionLds = size_t(transDoubles) * sizeof(double);
-    if (ctx->walkLds > 160 * 1024 || ctx->transitionLds > 160 * 1024)
+    ctx->launchLds = size_t(D.lds_total_launch) * sizeof(double);
+    if (ctx->walkLds > 160 * 1024 || ctx->launchLds > 160 * 1024)
         return bail(fail(PMC_ERR_UNSUPPORTED, "scene tables need more than 160 KiB of LDS"));
-    if (pmcConfigureKernels(ctx->walkLds, ctx->transitionLds) != hipSuccess)
+    if (pmcConfigureKernels(ctx->walkLds, ctx->launchLds) != hipSuccess)
         return bail(fail(PMC_ERR_DEVICE, "hipFuncSetAttribute failed"));
 
     // ---- launch geometry of the persistent walk kernel: as many workgroups as stay resident
@@ -1045,15 +1095,40 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         {
             unsigned long long perSlot = 128ull;
             if (const char* env = getenv("PMC_RF_LOG_PER_SLOT")) perSlot = std::max(1, atoi(env));  // (tests: a log that overflows)
-            const unsigned long long want = std::max<unsigned long long>(((unsigned long long)size[g] * perSlot + PMC_RF_LOG_CHUNK - 1) / PMC_RF_LOG_CHUNK, 1ull)
-                                            * PMC_RF_LOG_CHUNK;
+            // (the partition pass counts its entries in an int: at most 2^31 - 1 of them, in whole chunks; a wave that finds the log
+            // full adds its contributions atomically)
+            const unsigned long long want = std::min<unsigned long long>(
+                std::max<unsigned long long>(((unsigned long long)size[g] * perSlot + PMC_RF_LOG_CHUNK - 1) / PMC_RF_LOG_CHUNK, 1ull) * PMC_RF_LOG_CHUNK,
+                (0x7FFFFFFFull / PMC_RF_LOG_CHUNK) * PMC_RF_LOG_CHUNK);
             if (want <= ctx->rfCap[g]) continue;
             HIP_TRY(hipDeviceSynchronize());
+            // (a log that grows: the old buffers go first)
+            auto release = [&](void* p) {
+                if (!p) return;
+                hipFree(p);
+                auto at = std::find(ctx->rfAllocations.begin(), ctx->rfAllocations.end(), p);
+                if (at != ctx->rfAllocations.end()) ctx->rfAllocations.erase(at);
+            };
             for (int k = 0; k < 2; ++k)
             {
-                int rc;
-                if ((rc = ctx->allocate<uint32_t>(want, &ctx->rfKeys[g][k], false, &ctx->rfAllocations))) return rc;
-                if ((rc = ctx->allocate<double>(want, &ctx->rfVals[g][k], false, &ctx->rfAllocations))) return rc;
+                release(ctx->rfKeys[g][k]), release(ctx->rfVals[g][k]);
+                ctx->rfKeys[g][k] = nullptr, ctx->rfVals[g][k] = nullptr;
+            }
+            ctx->rfCap[g] = 0;
+            // no room for the log (24 bytes per entry): the group's contributions go to the table as atomics (cap 0)
+            size_t freeBytes = 0, totalBytes = 0;
+            bool room = hipMemGetInfo(&freeBytes, &totalBytes) != hipSuccess || size_t(want) * 24 + (size_t(1) << 30) <= freeBytes;
+            for (int k = 0; k < 2 && room; ++k)
+                room = ctx->allocate<uint32_t>(want, &ctx->rfKeys[g][k], false, &ctx->rfAllocations) == PMC_OK
+                       && ctx->allocate<double>(want, &ctx->rfVals[g][k], false, &ctx->rfAllocations) == PMC_OK;
+            if (!room)
+            {
+                for (int k = 0; k < 2; ++k)
+                {
+                    release(ctx->rfKeys[g][k]), release(ctx->rfVals[g][k]);
+                    ctx->rfKeys[g][k] = nullptr, ctx->rfVals[g][k] = nullptr;
+                }
+                continue;
             }
             ctx->rfCap[g] = want;
             size_t bytes = 0;
@@ -1062,7 +1137,11 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dk, dv, (int)std::min<unsigned long long>(want, 0x7FFFFFFFull), PMC_RF_BUCKET_BITS,
                                                        PMC_RF_BUCKET_BITS + std::max(1, rfSortBits)));
             bytes = std::max(bytes, ctx->rfTempBytes);
-            for (int h = 0; h < PMC_MAX_GROUPS; ++h) ctx->rfTemp[h] = nullptr;  // (all groups get temporaries of the largest size)
+            for (int h = 0; h < PMC_MAX_GROUPS; ++h)  // (all groups get temporaries of the largest size)
+            {
+                release(ctx->rfTemp[h]);
+                ctx->rfTemp[h] = nullptr;
+            }
             ctx->rfTempBytes = bytes;
         }
     if (rfLogged)
@@ -1157,13 +1236,13 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_LIVE(g), 0, sizeof(unsigned long long), sg));
             HIP_TRY(pmcLaunchTransition(ctx->slot, D.grid_kind, base[g], size[g], g, seed, transitionBlocks, ctx->transitionLds, sg));
-            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], g, first, count, seed, 0, launchBlocks, ctx->transitionLds, sg));
+            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], g, first, count, seed, 0, launchBlocks, ctx->launchLds, sg));
         }
         else
         {
             if (g > 0) HIP_TRY(hipStreamWaitEvent(sg, ctx->evStart, 0));
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
-            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], g, first, count, seed, 1, (size[g] + 255) / 256, ctx->transitionLds, sg));
+            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], g, first, count, seed, 1, (size[g] + 255) / 256, ctx->launchLds, sg));
         }
         HIP_TRY(hipEventRecord(ctx->evC[g], sg));
         HIP_TRY(hipMemcpyAsync(ctx->pinned + g, ctr + PMC_CTR_LIVE(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));

@@ -8,7 +8,9 @@
 //   neighbour CSR   int32                the reference's per-wall neighbour lists of every leaf, in the reference's
 //                                        order (cold: only read when a position is not strictly inside a candidate)
 //   Cartesian       double xv/yv/zv (staged in LDS), density double[num_cells]
-//   dust tables     lambda_border/sigma_ext/sigma_sca/asymmpar double[num_lambda] (staged in LDS when small)
+//   dust tables     lambda_border/sigma_ext/sigma_sca/asymmpar double[num_lambda]: the borders are staged in LDS by the launch
+//                                        kernel (the binary search of a history's wavelength); the properties of the bin found
+//                                        travel with the history in its slot
 // HBM, read-write:
 //   packet slots    struct-of-arrays over `num_slots` concurrently live photon histories (see SlotArrays)
 //   frames          double[frame_size]   detector arrays, accumulated with f64 atomics
@@ -110,7 +112,8 @@ struct SlotArrays
     uint64_t* history;
     double*  rngSpare;
     uint32_t* rngBlock;                     // (block << 1) | have
-    int32_t* dustIndex;                     // DustMix::indexForLambda(lambda)
+    double* dustExt; double* dustSca;       // extinction and scattering cross section of the dust mix at the history's wavelength
+    double* dustAsym;                       // and its asymmetry parameter: DustMix::indexForLambda(lambda) is looked up ONCE, at launch
     int32_t* mode;                          // bit 5 alive, bits 8-15 observers (group leaders) with a peel-off packet this cycle
     int32_t* nscatt;
     int32_t* pscatt;                        // numScatt of the cycle's peel-off packets (0: emission)
@@ -280,9 +283,12 @@ struct DevScene
     // ---- LDS carve-up (in doubles from the start of dynamic LDS; no kernel has static LDS, so that the octree
     //      coordinate table sits at LDS address 0 in all of them)
     int32_t lds_grid_len;          // all kernels: grid tables at offset 0
-    int32_t lds_dust_off;          // transition/launch kernels: dust tables (the walk kernel keeps sigma_ext after the grid)
-    int32_t lds_src_off, lds_sed_off, lds_sed_len, lds_hot_off, lds_sort_off, lds_total_transition, lds_total_walk;
-    int32_t dust_in_lds;
+    //      transition AND launch kernels: privatised SED blocks, hot-bin table, integer scratch (lds_total_transition doubles);
+    //      launch kernel only, behind them: Sersic tables of a single source, wavelength borders of the dust mix
+    //      (lds_total_launch doubles)
+    int32_t lds_dust_off;
+    int32_t lds_src_off, lds_sed_off, lds_sed_len, lds_hot_off, lds_sort_off, lds_total_transition, lds_total_launch, lds_total_walk;
+    int32_t dust_in_lds;           // the launch kernel stages the index borders of the dust mix (DustMix::_lambdav) in LDS
 };
 
 // The radiation-field contributions of the propagation walks of one slot group and generation (octree): (key, value)

@@ -7,24 +7,34 @@
 //      pass-2 walk (same path again, up to the sampled tau) -> interaction -> [peel-off walk per observer] ->
 //      scatter -> pass-1 walk ...
 //
-// >95 % of the work is in the walks: a pointer chase through the cell records in HBM/L2 with one dependent load and
-// about a hundred f64 instructions per step.  The loop is split into TWO kernels that run alternately over a pool of
-// `num_slots` concurrently live histories whose state lives in HBM (struct of arrays):
+// >70 % of the work is in the walks: a pointer chase through the cell records in HBM / L2 with one dependent gather and
+// about 120-150 f64 instructions per step.  The loop runs over a pool of `num_slots` concurrently live histories whose
+// state lives in HBM (struct of arrays, pmc_device.h SlotArrays), divided into slot groups with a stream each; ONE
+// generation of a group = one scattering cycle of every live slot of the group, and is five kernels (generation 6,
+// DESIGN.md section 4):
 //
-//   walkKernel        (pmc_walk.inc) lean (few registers -> many waves per SIMD).  Persistent wavefronts, one walk per
-//                     lane, a straight-line step per cell visit.  Lanes whose walk has ended (or that need the rare
-//                     literal reference algorithm) are served together when enough of them wait: results are written
-//                     and the next slots are taken from a chunked global cursor.  No random numbers, no
-//                     transcendental functions, no division in the step.
-//   transitionKernel  (pmc_transition.inc) one lane per slot: consumes the walk result, does the divergent physics
-//                     (detection with atomics, sampling, HG scattering, launching the next history from the global
-//                     history cursor) and leaves the next walk task in the slot.  All random draws happen here, from
-//                     the slot's own Philox stream keyed by (seed, history index) (include/pmc_philox.h).
+//   walkPropKernel    (pmc_walk_tree.inc, octree) the propagation walk of every slot: pass 1 over the whole path, the
+//                     sampled optical depth between the passes, pass 2 up to it -- from the first recorded segments in
+//                     LDS where the interaction lies within them.  Persistent wavefronts, one walk per lane, per-lane
+//                     directions; lanes whose walk has ended are served together in bookkeeping rounds.
+//   walkPeelKernel2   (pmc_walk_tree.inc, octree; one launch per observer, on a side stream next to the propagation
+//                     kernel) the peel-off walks towards one observer: the direction lives in scalar registers, every
+//                     wave keeps a queue of task records in LDS from which a lane takes its next walk by itself.
+//                     (walkKernel in pmc_walk.inc is the generic form for Cartesian and Voronoi grids: all walks of a
+//                     slot one after the other in one lane.)
+//   transitionKernel  (pmc_transition.inc) one lane per live slot, every wave working through its own compacted list:
+//                     detection of the cycle's peel-off packets (FluxRecorder::detect: privatised SED bins and a
+//                     claim-once hot-bin table in LDS in front of f64 atomics, per-history statistics lists), the
+//                     interaction the propagation walk found (weights, termination), HG scattering from the slot's
+//                     Philox stream keyed by (seed, history index) (include/pmc_philox.h), and the start state of every
+//                     walk of the next cycle (task records, pmc_device.h TaskArrays).
+//   endedScanKernel   exclusive scan of the per-tile counts of histories that ended: the history index a slot takes up
+//                     next is a pure function of the slot order.
+//   launchKernel      one lane per ended history: flush of its statistics list, SourceSystem::launch of the next
+//                     history, first cycle.
 //
-// One generation = walkKernel + transitionKernel; a history needs about 3 generations per scattering event.  The
-// host enqueues generations until no slot is alive (pmc_api.hip); the pool is split into slot groups whose
-// generations are enqueued on separate streams, so that the tail of one group's walk kernel and its latency-bound
-// transition kernel overlap with the walk kernel of the other group.
+// The host enqueues generations until no slot is alive (pmc_api.hip); one 8-byte readback per generation and group tells
+// it when a group is done, and the kernels of the other groups keep the device busy meanwhile.
 //
 // The reference stores the whole path (<= 1000 x 40 B per thread) and binary-searches the interaction point
 // (SpatialGridPath.cpp:164-206).  Here the path is walked twice with bit-identical arithmetic instead: pass 1 yields
@@ -35,14 +45,17 @@
 // traversal must produce the same (m, ds) sequence bit for bit (pmc_trace_ray).  The only fused operations are the
 // explicit ones in exactQuotient (pmc_walk.inc), which reproduce IEEE division.
 //
-// Octree traversal (TreeSpatialGrid.cpp:132-217): the reference hops through per-wall neighbour lists of heap
-// nodes.  Here a walk step issues ONE 16-byte gather from a table split by exit axis (pmc_device.h AxisRec: the cell's
-// density and the links through the two walls of that axis); wall coordinates come from a per-axis table staged in LDS
-// (exactly the reference's doubles).  A link leads to the leaf covering the whole wall (same size or coarser) or to
-// the same-size internal node (finer neighbours), from which the position descends by its index bits.  This gives the reference's answer whenever the
-// new position lies strictly inside the leaf found; in every other case (position on a shared boundary, corner
-// overshoot, rounding, grid boundary) the code falls back to the literal reference algorithm on the neighbour lists
-// kept in HBM in the reference's order, followed by the reference's top-down search and next-after escape.
+// Octree traversal (TreeSpatialGrid.cpp:132-217): the reference hops through per-wall neighbour lists of heap nodes.
+// Here a walk step gathers ONE 32-byte record of the cell it is in (pmc_device.h CellRec: density + the six links
+// through its walls; two 16-byte loads of one sector), requested as soon as the cell is known, i.e. before the arithmetic
+// that enters the cell; wall coordinates come from a per-axis table staged in LDS (exactly the reference's doubles).  A
+// link names the leaf that covers the whole wall (same size or coarser) together with its size exponent, so that the
+// box follows from the packed indices of the current cell without a load; or the same-size internal node (finer
+// neighbours), from which the child follows from the index bits of the position -- without a load when the node's
+// children are all leaves (consecutive cells in depth-first order).  This gives the reference's answer whenever the new
+// position lies strictly inside the leaf found; in every other case (position on a shared boundary, corner overshoot,
+// rounding, grid boundary) the code falls back to the literal reference algorithm on the neighbour lists kept in HBM in
+// the reference's order, followed by the reference's top-down search and next-after escape.
 
 #include "pmc_device.h"
 #include "../../include/pmc_philox.h"

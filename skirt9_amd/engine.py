@@ -63,6 +63,10 @@ def lib():
         L.pmc_set_num_slots.argtypes = [C.c_void_p, C.c_int64]
         L.pmc_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                       C.POINTER(C.c_int32)]
+        if os.environ.get("PMC_LIBRARY") and not hasattr(L, "pmc_walk_work"):
+            # (kernel A/B experiments against an engine built from an older commit: tools/sweep.py copes without these)
+            _lib = L
+            return _lib
         L.pmc_last_walk_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.pmc_walk_work.argtypes = [C.c_void_p, C.POINTER(WalkWork)]
         L.pmc_radiation_field_size.restype = C.c_int64
