@@ -36,10 +36,11 @@ extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlo
 extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, int cursor, uint64_t seed, int grid,
                                     size_t ldsBytes, const RfLogArgs* rfLog, hipStream_t stream);
 extern "C" hipError_t pmcLaunchRfReduce(int slot, const uint32_t* keys, const double* vals, unsigned long long n, int numBuckets, hipStream_t stream);
-extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, uint64_t seed, int maxBlocks,
-                                          size_t ldsBytes, hipStream_t stream);
-extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int group, uint64_t first, uint64_t count,
-                                      uint64_t seed, int initial, int maxBlocks, size_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, int maxBlocks, size_t ldsBytes,
+                                          hipStream_t stream);
+extern "C" hipError_t pmcLaunchLaunch(int slot, int slotBase, int numSlots, int group, uint64_t first, uint64_t count, uint64_t seed, int initial,
+                                      int maxBlocks, size_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int maxBlocks, size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchTrace(int slot, int gridKind, int wide, int uniform, const double r[3], const double k[3],
                                      const double* kdev, int32_t* m, double* ds, int32_t cap, int32_t* n, size_t ldsBytes,
                                      hipStream_t stream);
@@ -481,8 +482,7 @@ namespace
         if ((rc = ctx->allocate<double>(size_t(n) * size_t(ctx->dev.num_instruments), &A.ppW, false, &own))) return rc;
         if ((rc = ctx->allocate<double>(size_t(n) * size_t(ctx->dev.num_instruments), &A.ptau, false, &own))) return rc;
         if ((rc = ctx->allocate<int32_t>(size_t(n) * size_t(ctx->dev.num_instruments), &A.ell, true, &own))) return rc;
-        if ((rc = ctx->allocate<int32_t>(size_t(n) * size_t(ctx->dev.num_instruments), &A.nstat, true, &own))) return rc;
-        if ((rc = ctx->allocate<int32_t>(size_t(n) * size_t(ctx->dev.num_instruments), &A.statNext, false, &own))) return rc;
+        if (ctx->dev.any_stats && (rc = ctx->allocate<int32_t>(size_t(n) * size_t(ctx->dev.num_instruments) * 16, &A.statHead, true, &own))) return rc;
         if (ctx->dev.rf_store && (rc = ctx->allocate<int32_t>(n, &A.rfell, true, &own))) return rc;
         if (ctx->dev.any_stats)
         {
@@ -803,8 +803,8 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     if ((rc = ctx->upload(med.sigma_ext, med.num_lambda, &D.sigma_ext))) return bail(rc);
     if ((rc = ctx->upload(med.sigma_sca, med.num_lambda, &D.sigma_sca))) return bail(rc);
     if ((rc = ctx->upload(med.asymmpar, med.num_lambda, &D.asymmpar))) return bail(rc);
-    int walkDoubles = D.lds_grid_len;
-    int transDoubles = D.lds_grid_len;  // the grid tables come first in every kernel
+    int walkDoubles = D.lds_grid_len;   // walk kernels and cycle start kernel: the grid tables, at offset 0
+    int transDoubles = 0;               // transition and launch kernels: no grid tables
     int launchOnlyDoubles = 0;          // what only the launch kernel stages, behind the regions the two kernels share
 
     D.force_scattering = scene->options.force_scattering;
@@ -1201,6 +1201,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     HIP_TRY(hipEventRecord(ctx->evStart, st));
     int launchBlocks = ctx->numCU * 4;  // persistent launch workgroups, as the transition kernel's
     if (const char* env = getenv("PMC_LAUNCH_BLOCKS_PER_CU")) launchBlocks = ctx->numCU * std::max(1, atoi(env));
+    int cycleBlocks = ctx->numCU * 4;  // persistent cycle start workgroups (grid tables staged once per workgroup)
+    if (const char* env = getenv("PMC_CYCLE_BLOCKS_PER_CU")) cycleBlocks = ctx->numCU * std::max(1, atoi(env));
     int transitionBlocks = ctx->numCU * 4;  // persistent transition workgroups (tables staged once per workgroup)
     if (const char* env = getenv("PMC_TRANSITION_BLOCKS_PER_CU")) transitionBlocks = ctx->numCU * std::max(1, atoi(env));
     auto enqueue = [&](int g, bool initial) -> int {
@@ -1235,15 +1237,17 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             haveWalk[g] = true;
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_LIVE(g), 0, sizeof(unsigned long long), sg));
-            HIP_TRY(pmcLaunchTransition(ctx->slot, D.grid_kind, base[g], size[g], g, seed, transitionBlocks, ctx->transitionLds, sg));
-            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], g, first, count, seed, 0, launchBlocks, ctx->launchLds, sg));
+            HIP_TRY(pmcLaunchTransition(ctx->slot, base[g], size[g], g, seed, transitionBlocks, ctx->transitionLds, sg));
+            HIP_TRY(pmcLaunchLaunch(ctx->slot, base[g], size[g], g, first, count, seed, 0, launchBlocks, ctx->launchLds, sg));
         }
         else
         {
             if (g > 0) HIP_TRY(hipStreamWaitEvent(sg, ctx->evStart, 0));
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
-            HIP_TRY(pmcLaunchLaunch(ctx->slot, D.grid_kind, base[g], size[g], g, first, count, seed, 1, (size[g] + 255) / 256, ctx->launchLds, sg));
+            HIP_TRY(pmcLaunchLaunch(ctx->slot, base[g], size[g], g, first, count, seed, 1, (size[g] + 255) / 256, ctx->launchLds, sg));
         }
+        // every live slot of the group is at the start of a cycle now: the start states of its walks
+        HIP_TRY(pmcLaunchCycleStart(ctx->slot, D.grid_kind, base[g], size[g], cycleBlocks, ctx->walkLds, sg));
         HIP_TRY(hipEventRecord(ctx->evC[g], sg));
         HIP_TRY(hipMemcpyAsync(ctx->pinned + g, ctr + PMC_CTR_LIVE(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
         if (rfLogged && !initial)

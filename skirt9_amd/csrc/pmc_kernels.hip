@@ -109,6 +109,12 @@
                                   // registers left to itself (two waves per SIMD) and runs 3 % faster with three (168 registers, 92
                                   // bytes of scratch): its visits are three dependent round trips
 #endif
+#ifndef PMC_LAUNCH_MIN_WAVES
+    #define PMC_LAUNCH_MIN_WAVES 2  // launch kernel (statistics flush + source sampling)
+#endif
+#ifndef PMC_CYCLE_MIN_WAVES
+    #define PMC_CYCLE_MIN_WAVES 4  // cycle start kernel (first cell and first exit distance of every walk of a cycle): 113 registers
+#endif
 #ifndef PMC_TRANSITION_MIN_WAVES
     #define PMC_TRANSITION_MIN_WAVES 2  // likewise for the transition and launch kernels (256 registers: two waves per SIMD; left to
                                         // itself the compiler takes 262 and halves the occupancy)
@@ -268,15 +274,14 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
                {reinterpret_cast<const void*>(&walkKernel<GRID_CART, false>), walkMax},
                {reinterpret_cast<const void*>(&walkKernel<GRID_CART, true>), walkMax},
                {reinterpret_cast<const void*>(&traceRayKernel<GRID_CART>), walkMax},
-               {reinterpret_cast<const void*>(&transitionKernel<GRID_TREE>), transitionMax},
-               {reinterpret_cast<const void*>(&transitionKernel<GRID_CART>), transitionMax},
-               {reinterpret_cast<const void*>(&launchKernel<GRID_TREE>), transitionMax},
-               {reinterpret_cast<const void*>(&launchKernel<GRID_CART>), transitionMax},
+               {reinterpret_cast<const void*>(&transitionKernel), transitionMax},
+               {reinterpret_cast<const void*>(&launchKernel), transitionMax},
+               {reinterpret_cast<const void*>(&cycleStartKernel<GRID_TREE>), walkMax},
+               {reinterpret_cast<const void*>(&cycleStartKernel<GRID_CART>), walkMax},
+               {reinterpret_cast<const void*>(&cycleStartKernel<GRID_VORO>), walkMax},
                {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false>), walkMax},
                {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, true>), walkMax},
-               {reinterpret_cast<const void*>(&traceRayKernel<GRID_VORO>), walkMax},
-               {reinterpret_cast<const void*>(&transitionKernel<GRID_VORO>), transitionMax},
-               {reinterpret_cast<const void*>(&launchKernel<GRID_VORO>), transitionMax}};
+               {reinterpret_cast<const void*>(&traceRayKernel<GRID_VORO>), walkMax}};
     for (const auto& k : all)
     {
         hipError_t e = hipFuncSetAttribute(k.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds);
@@ -317,6 +322,7 @@ extern "C" int pmcPropBlock(void)
 {
     return PMC_PROP_BLOCK;
 }
+
 
 // walks of the task records [taskBase, taskBase + numTaskRecords) of one slot group on a Cartesian or Voronoi grid;
 // taskCounter = index of the group's (zeroed) cursor
@@ -386,17 +392,12 @@ extern "C" hipError_t pmcLaunchStatMerge(int slot, int blocks, hipStream_t strea
 
 // transitions of the slots [slotBase, slotBase + numSlots) of slot group `group`, followed by the scan of the group's
 // ended-history counts (the launch kernel's history indices)
-extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, int numSlots, int group, uint64_t seed, int maxBlocks,
-                                          size_t ldsBytes, hipStream_t stream)
+extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, int maxBlocks, size_t ldsBytes,
+                                          hipStream_t stream)
 {
     const int block = PMC_TRANSITION_BLOCK;
     const int grid = std::max(1, std::min((numSlots + block - 1) / block, maxBlocks));
-    if (gridKind == PMC_GRID_OCTREE)
-        hipLaunchKernelGGL(transitionKernel<GRID_TREE>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group, seed);
-    else if (gridKind == PMC_GRID_VORONOI)
-        hipLaunchKernelGGL(transitionKernel<GRID_VORO>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group, seed);
-    else
-        hipLaunchKernelGGL(transitionKernel<GRID_CART>, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group, seed);
+    hipLaunchKernelGGL(transitionKernel, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group, seed);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(endedScanKernel, dim3(1), dim3(1024), 0, stream, slot, slotBase, numSlots, group);
@@ -404,19 +405,24 @@ extern "C" hipError_t pmcLaunchTransition(int slot, int gridKind, int slotBase, 
 }
 
 // launches of new histories into the slots of the group whose history ended (initial: into all slots of the group)
-extern "C" hipError_t pmcLaunchLaunch(int slot, int gridKind, int slotBase, int numSlots, int group, uint64_t first, uint64_t count,
-                                      uint64_t seed, int initial, int maxBlocks, size_t ldsBytes, hipStream_t stream)
+extern "C" hipError_t pmcLaunchLaunch(int slot, int slotBase, int numSlots, int group, uint64_t first, uint64_t count, uint64_t seed, int initial,
+                                      int maxBlocks, size_t ldsBytes, hipStream_t stream)
+{
+    const int grid = std::max(1, std::min((numSlots + 255) / 256, maxBlocks));
+    hipLaunchKernelGGL(launchKernel, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, first, count, seed, initial);
+    return hipGetLastError();
+}
+
+// the walks of the cycle that every live slot of the group is about to start (task records)
+extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int maxBlocks, size_t ldsBytes, hipStream_t stream)
 {
     const int grid = std::max(1, std::min((numSlots + 255) / 256, maxBlocks));
     if (gridKind == PMC_GRID_OCTREE)
-        hipLaunchKernelGGL(launchKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, first, count, seed,
-                           initial);
+        hipLaunchKernelGGL(cycleStartKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots);
     else if (gridKind == PMC_GRID_VORONOI)
-        hipLaunchKernelGGL(launchKernel<GRID_VORO>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, first, count, seed,
-                           initial);
+        hipLaunchKernelGGL(cycleStartKernel<GRID_VORO>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots);
     else
-        hipLaunchKernelGGL(launchKernel<GRID_CART>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, first, count, seed,
-                           initial);
+        hipLaunchKernelGGL(cycleStartKernel<GRID_CART>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots);
     return hipGetLastError();
 }
 
