@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --packets is the TOTAL per step, split over the ranks by history range (e.g. "
                          "--config 4 --packets 1e9 --gpus 8 = BASELINE configs[3]); default: weak scaling, --packets per GPU")
+    ap.add_argument("--sites", type=float, default=1e5, help="--config 5: number of Voronoi sites (BASELINE configs[4]: 1e5)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the second measurement of the default run (the same octree with a uniform-box source)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,7 +125,7 @@ def main():
     import torch
     import torch.distributed as dist
     from skirt9_amd.engine import Engine
-    from skirt9_amd.host import Simulation
+    from skirt9_amd.host import SceneFile, Simulation
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -166,8 +167,7 @@ def main():
 
     P = int(args.packets)
     total_per_step = P if args.strong else P * world
-    if world > 1:
-        os.environ.setdefault("SKH_THREADS", str(max(1, (os.cpu_count() or 1) // world)))  # host setup threads per rank
+    # (N > 1: rank 0 alone sets the scene up, with all host cores, and the others load the file it saves: measure() below)
     if args.config == 3:
         if args.ski != SKI or args.source != "sersic":
             raise SystemExit("--config 3 selects its own ski file and source")
@@ -177,16 +177,18 @@ def main():
             raise SystemExit("--config 5 selects its own ski file and source")
         args.ski = os.path.join(ROOT, "tests", "ski", "cfg5.ski")
         sitedir = tempfile.mkdtemp(prefix=f"bench_sites_r{rank}_")
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_sites.py"), "--n", "100000", "--seed", "1",
-                               os.path.join(sitedir, "cfg5_sites.txt")])
+        if rank == 0 or world == 1:
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_sites.py"), "--n", str(int(args.sites)), "--seed", "1",
+                                   os.path.join(sitedir, "cfg5_sites.txt")])
         os.environ["SKH_INPUT_PATH"] = sitedir
     if args.config == 4:
         if args.ski != SKI or args.source != "sersic":
             raise SystemExit("--config 4 selects its own ski file and source")
         args.ski = os.path.join(ROOT, "tests", "ski", "cfg4.ski")
         sphdir = tempfile.mkdtemp(prefix=f"bench_sph_r{rank}_")
-        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_sph.py"), "--n", "1000000", "--seed", "1",
-                               os.path.join(sphdir, "cfg4_sph.txt")])
+        if rank == 0 or world == 1:
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_sph.py"), "--n", "1000000", "--seed", "1",
+                                   os.path.join(sphdir, "cfg4_sph.txt")])
         os.environ["SKH_INPUT_PATH"] = sphdir
     # every rank sets up the same scene (replica of grid, densities, tables); numPackets = packets of one step over
     # all ranks, so that the per-packet luminosity is that of the whole segment
@@ -218,10 +220,25 @@ def main():
     def measure(path, steps, warmup):
         """sets the scene of ski file `path` up on this rank's GPU and times `steps` segments; returns the numbers of the
         JSON line (rank 0) -- value, roofline inputs, counters"""
-        sim = Simulation(path, num_packets=total_per_step)
-        if args.config == 4:
-            sim.use_device_sampler(local_rank)  # setup-time density sampling of the particle medium on this rank's GPU
-        sim.setup()
+        # Every rank needs a replica of the scene.  ONE rank sets it up (all host cores) and saves it as one file in /dev/shm
+        # (skh_scene_save); the others load that file -- no second tree construction, no second density sampling.
+        sim = None
+        cache = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir(),
+                             f"pmc_scene_{os.environ.get('MASTER_PORT', '0')}_{os.path.basename(path)}_{total_per_step}.bin")
+        if rank == 0:
+            sim = Simulation(path, num_packets=total_per_step)
+            if args.config == 4:
+                sim.use_device_sampler(local_rank)  # setup-time density sampling of the particle medium on this rank's GPU
+            sim.setup()
+            if world > 1:
+                sim.save_scene(cache)
+        if world > 1:
+            dist.barrier()
+            if rank != 0:
+                sim = SceneFile(cache)
+            dist.barrier()
+            if rank == 0:
+                os.unlink(cache)
         eng = Engine(sim.scene, local_rank)
         frames = torch.zeros(sim.frame_size, dtype=torch.float64, device=f"cuda:{local_rank}")
         eng.bind_frames(frames.data_ptr(), frames.numel())
@@ -405,7 +422,7 @@ def main():
                                     "wavelength grid, tabulated dust mix (2102-point opacity table)"
                                     if args.config == 3 else
                                     f"BASELINE configs[4]: Sersic source, VoronoiMeshSpatialGrid of {main_run['cells']} sites (tools/make_sites.py "
-                                    "--n 100000 --seed 1), panchromatic 0.1-10 micron, 20 bins, THREE FullInstruments 256^2"
+                                    f"--n {int(args.sites)} --seed 1), panchromatic 0.1-10 micron, 20 bins, THREE FullInstruments 256^2"
                                     if args.config == 5 else
                                     "BASELINE configs[3]: Sersic source, dust imported from 10^6 smoothed particles "
                                     f"(tools/make_sph.py --n 1000000 --seed 1), {main_run['cells']}-cell density-policy octree")
@@ -439,12 +456,20 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.ski if args.source == "sersic" else ski_path, os.environ.get("SKH_INPUT_PATH"))
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     if comm is not None:
         comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    # the JSON line is the LAST thing on stdout: whatever the communication libraries have printed through C stdio (version
+    # banners) is flushed first
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -49,6 +49,19 @@ int64_t  skh_radiation_field_size(const skh_simulation* sim);
 int skh_write_radiation_field(const skh_simulation* sim, const double* rf, const char* outdir);
 int skh_summary(const skh_simulation* sim, char* buffer, int32_t capacity);
 
+/* A set-up scene as ONE file: everything pmc_create reads plus the numbers a driver of the photon loop needs.  In a job of
+   one process per GPU, one process sets the simulation up (all host cores) and saves it, the others load it instead of
+   repeating the setup -- the reference repeats Simulation::setupSimulation in every MPI process.  A loaded scene serves
+   pmc_create and the frame layout; the output files are written by the process that holds the simulation. */
+int skh_scene_save(const skh_simulation* sim, const char* path);
+typedef struct skh_scene_file skh_scene_file;
+skh_scene_file* skh_scene_load(const char* path);
+void skh_scene_file_free(skh_scene_file* file);
+const pmc_scene* skh_scene_file_scene(const skh_scene_file* file);
+enum { SKH_SCENE_SEED = 0, SKH_SCENE_NUM_PACKETS = 1, SKH_SCENE_FRAME_SIZE = 2, SKH_SCENE_RADIATION_FIELD_SIZE = 3, SKH_SCENE_SETUP_DRAWS = 4 };
+int64_t skh_scene_file_number(const skh_scene_file* file, int32_t what);
+int skh_scene_file_layout(const skh_scene_file* file, int32_t instrument, pmc_frame_layout* out);
+
 #ifdef __cplusplus
 }
 #endif

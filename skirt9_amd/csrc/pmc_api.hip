@@ -21,6 +21,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 extern "C" hipError_t pmcUploadScene(int slot, const DevScene* scene, hipStream_t stream);
@@ -715,10 +716,13 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
             // e1, e1 + e2, e1 + e3 | e2, e1 + e2, e2 + e3 | e3, e1 + e3, e2 + e3 | e1 + e2, e1 + e3, e2 + e3)
             static const int sub[4][3][3] = {{{1, 0, 0}, {1, 1, 0}, {1, 0, 1}}, {{0, 1, 0}, {1, 1, 0}, {0, 1, 1}}, {{0, 0, 1}, {1, 0, 1}, {0, 1, 1}},
                                              {{1, 1, 0}, {1, 0, 1}, {0, 1, 1}}};
+            // 32-bit masks, 768 bytes per cell: a cell of the 10^5- and 10^6-site grids of the BASELINE scene has 15.2 / 15.4
+            // neighbours on average, 99 % of the cells at most 24, 35 at most (neighbours beyond the 32nd are always read)
             const int ncell = g.num_cells;
-            std::vector<unsigned long long> cull(size_t(ncell) * PMC_VORO_CONES, 0ull);
-            for (int m = 0; m < ncell; ++m)
-                for (int q = g.vnbr_start[m]; q < g.vnbr_start[m + 1] && q - g.vnbr_start[m] < 64; ++q)
+            std::vector<uint32_t> cull(size_t(ncell) * PMC_VORO_CONES, 0u);
+            auto cullCells = [&](int mFirst, int mLast) {
+            for (int m = mFirst; m < mLast; ++m)
+                for (int q = g.vnbr_start[m]; q < g.vnbr_start[m + 1] && q - g.vnbr_start[m] < 32; ++q)
                 {
                     const int j = q - g.vnbr_start[m];
                     const int mi = g.vnbr_list[q];
@@ -759,10 +763,19 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
                                     const bool negative = ((sgn >> (wall >> 1)) & 1) != 0;
                                     skip = (wall & 1) ? negative : !negative;
                                 }
-                                if (skip) cull[size_t(m) * PMC_VORO_CONES + (sgn * 6 + p) * (PMC_VORO_CONES / 48) + c] |= 1ull << j;
+                                if (skip) cull[size_t(m) * PMC_VORO_CONES + (sgn * 6 + p) * (PMC_VORO_CONES / 48) + c] |= 1u << j;
                             }
                         }
                 }
+            };
+            {
+                // (cells are independent: all host cores)
+                const int workers = std::max(1, std::min<int>(64, (int)std::thread::hardware_concurrency()));
+                std::vector<std::thread> pool;
+                for (int t = 0; t < workers; ++t)
+                    pool.emplace_back(cullCells, int(int64_t(ncell) * t / workers), int(int64_t(ncell) * (t + 1) / workers));
+                for (auto& t : pool) t.join();
+            }
             if ((rc = ctx->upload(cull.data(), cull.size(), &D.vcull))) return bail(rc);
         }
         D.vblock_n = g.vblock_n;

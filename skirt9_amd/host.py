@@ -95,6 +95,15 @@ def lib():
         L.skh_radiation_field_size.restype = C.c_int64
         L.skh_radiation_field_size.argtypes = [C.c_void_p]
         L.skh_write_radiation_field.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+        L.skh_scene_save.argtypes = [C.c_void_p, C.c_char_p]
+        L.skh_scene_load.restype = C.c_void_p
+        L.skh_scene_load.argtypes = [C.c_char_p]
+        L.skh_scene_file_free.argtypes = [C.c_void_p]
+        L.skh_scene_file_scene.restype = C.c_void_p
+        L.skh_scene_file_scene.argtypes = [C.c_void_p]
+        L.skh_scene_file_number.restype = C.c_int64
+        L.skh_scene_file_number.argtypes = [C.c_void_p, C.c_int32]
+        L.skh_scene_file_layout.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FrameLayout)]
         _lib = L
     return _lib
 
@@ -192,6 +201,13 @@ class Simulation:
         if lib().skh_write_radiation_field(self._h, data.ctypes.data_as(C.c_void_p), os.fsencode(outdir)) != 0:
             raise RuntimeError(lib().skh_last_error().decode())
 
+    def save_scene(self, path):
+        """the set-up scene as one file (skh_scene_save): other processes of a multi-GPU job load it with SceneFile instead of
+        repeating the setup"""
+        assert self._setup, "call setup() first"
+        if lib().skh_scene_save(self._h, os.fsencode(path)) != 0:
+            raise RuntimeError(lib().skh_last_error().decode())
+
     def summary(self):
         buf = C.create_string_buffer(2048)
         lib().skh_summary(self._h, buf, len(buf))
@@ -206,3 +222,46 @@ class Simulation:
         if lib().skh_write(self._h, data.ctypes.data_as(C.c_void_p), os.fsencode(outdir)) != 0:
             raise RuntimeError(lib().skh_last_error().decode())
         return data
+
+
+class SceneFile:
+    """A scene saved by ``Simulation.save_scene``: what the engine needs (``scene``, ``seed``, ``frame_size``, ``layout``,
+    ``radiation_field_size``), without the model behind it -- the process that holds the Simulation writes the output."""
+
+    def __init__(self, path):
+        L = lib()
+        self.path = str(path)
+        self._f = L.skh_scene_load(os.fsencode(path))
+        if not self._f:
+            raise RuntimeError(L.skh_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_f", None):
+            lib().skh_scene_file_free(self._f)
+            self._f = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def scene(self):
+        return lib().skh_scene_file_scene(self._f)
+
+    def _number(self, what):
+        return int(lib().skh_scene_file_number(self._f, what))
+
+    seed = property(lambda self: self._number(0))
+    num_packets = property(lambda self: self._number(1))
+    frame_size = property(lambda self: self._number(2))
+    radiation_field_size = property(lambda self: self._number(3))
+    setup_draws = property(lambda self: self._number(4))
+
+    def layout(self, instrument=0):
+        out = FrameLayout()
+        if lib().skh_scene_file_layout(self._f, instrument, C.byref(out)) != 0:
+            raise IndexError(instrument)
+        return out
+

@@ -16,6 +16,13 @@ namespace
     }
 }
 
+// error text of the calling thread, for the other translation units of the library (scenefile.cpp)
+const char* skh_set_error_text(const std::string& text)
+{
+    t_error = text;
+    return t_error.c_str();
+}
+
 struct skh_simulation
 {
     std::unique_ptr<skh::Simulation> sim;
