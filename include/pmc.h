@@ -42,10 +42,10 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 5
+#define PMC_ABI_VERSION 6
 
 enum { PMC_OK = 0, PMC_ERR_INVALID = -1, PMC_ERR_UNSUPPORTED = -2, PMC_ERR_DEVICE = -3, PMC_ERR_NOMEM = -4,
-       PMC_ERR_OVERFLOW = -5 /* a history contributed to more distinct pixels than the statistics list holds */ };
+       PMC_ERR_OVERFLOW = -5 /* the pool of statistics-list blocks ran out during the segment (see pmc_run_primary) */ };
 
 /* ---------------------------------------------------------------- spatial grid ---- */
 
@@ -276,9 +276,12 @@ int pmc_clear_frames(pmc_ctx* ctx);
    stay on the device; pmc_download copies them).  The RNG stream of a history depends only on (seed, history
    index), so any partition of [0,Npp) over calls and devices gives the same result up to the summation order of
    the floating-point atomics.
-   FluxRecorder::recordContributions keeps every contribution of a history (FluxRecorder.cpp:962-1014); the engine's
-   per-history list holds PMC_STAT_CAP = 48 DISTINCT pixels per instrument.  If a history of the segment exceeded that,
-   the statistics arrays are wrong and the call returns PMC_ERR_OVERFLOW (the flux arrays are unaffected). */
+   FluxRecorder::recordContributions keeps every contribution of a history (FluxRecorder.cpp:962-1014, FluxRecorder.hpp:327-338:
+   an unbounded list).  The engine keeps one entry per DISTINCT pixel of a history and instrument: four in a head record of the
+   history's slot, 44 more in the slot's own list, the rest in chained blocks of 48 entries from a device pool (default: one block per
+   four slots, more for a ski file with a large minScattEvents; environment PMC_STAT_POOL_BLOCKS).  Only if that pool runs out
+   during a segment are statistics lost: the call then returns PMC_ERR_OVERFLOW (the flux arrays are unaffected, the statistics
+   arrays of the segment are incomplete, the next segment starts with a full pool). */
 int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed);
 int pmc_sync(pmc_ctx* ctx);
 int pmc_download(pmc_ctx* ctx, double* host_frames, int64_t num_doubles);
