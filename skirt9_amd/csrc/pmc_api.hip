@@ -1328,14 +1328,19 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     };
     for (int g = 0; g < PMC_MAX_GROUPS; ++g) ctx->pinned[PMC_MAX_GROUPS + g] = 0;
     if (int rc = drive()) return abandon(rc);
-    // (the last radiation-field logs of the groups are reduced on their streams)
-    if (rfLogged)
-        for (int g = 0; g < G; ++g) HIP_TRY(hipStreamSynchronize(ctx->groupStream[g]));
-    // the segment's statistics: accumulator records -> wifu arrays (every group's stream has been waited for)
-    if (D.stat_acc_records) HIP_TRY(pmcLaunchStatMerge(ctx->slot, ctx->numCU * 8, st));
-    HIP_TRY(hipEventRecord(ctx->evStop, st));
-    HIP_TRY(hipEventSynchronize(ctx->evStop));
-    HIP_TRY(hipEventElapsedTime(&ctx->totalMs, ctx->evStart, ctx->evStop));
+    // the end of the segment (a failure here leaves the segment abandoned like one in the generations)
+    auto finish = [&]() -> int {
+        // (the last radiation-field logs of the groups are reduced on their streams)
+        if (rfLogged)
+            for (int g = 0; g < G; ++g) HIP_TRY(hipStreamSynchronize(ctx->groupStream[g]));
+        // the segment's statistics: accumulator records -> wifu arrays (every group's stream has been waited for)
+        if (D.stat_acc_records) HIP_TRY(pmcLaunchStatMerge(ctx->slot, ctx->numCU * 8, st));
+        HIP_TRY(hipEventRecord(ctx->evStop, st));
+        HIP_TRY(hipEventSynchronize(ctx->evStop));
+        HIP_TRY(hipEventElapsedTime(&ctx->totalMs, ctx->evStart, ctx->evStop));
+        return PMC_OK;
+    };
+    if (int rc = finish()) return abandon(rc);
     ctx->walkMs = walkMs;
     ctx->transitionMs = transMs;
     ctx->peelMs = peelMs;

@@ -14,6 +14,7 @@ Fixtures:
   cfg3z_*      the reduced config-3 scene at model redshift 0.5 (FlatUniverseCosmology) with SIX instruments, three of them in
                the observer frame (distance 0: wavelength bins at lambda (1+z), cosmological distances) -> files
   cfg1nf_*     non-forced scattering variant of config 1 (tests/ski/cfg1nf.ski): 2x10^5 packets -> files
+  cfg2nf_*     non-forced scattering on the octree of reduced config 2 (tests/ski/cfg2nf.ski) -> files
   cfg1sed_*    config 1 with two SEDInstruments next to the FullInstrument (tests/ski/cfg1sed.ski): 10^5 packets -> files
   cfg3sed_*    reduced config 3 with a FileSED source spectrum (tests/ski/cfg3sed.ski + cfg3sed_sed.txt) -> files
   cfg3norm_*   the same with a SpecificLuminosityNormalization (per unit of frequency): SED files only
@@ -101,7 +102,7 @@ def rays_config2():
 def main():
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
-    for name, scale in (("cfg1", 3.08567758e16), ("cfg1mesh", 3.08567758e16), ("cfg1mesh2", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg2deep", 300 * 3.08567758e16), ("cfg3small", None), ("cfg3z", None), ("cfg1nf", None),
+    for name, scale in (("cfg1", 3.08567758e16), ("cfg1mesh", 3.08567758e16), ("cfg1mesh2", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg2deep", 300 * 3.08567758e16), ("cfg3small", None), ("cfg3z", None), ("cfg1nf", None), ("cfg2nf", None),
                         ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1sed", None), ("cfg3sed", None), ("cfg3norm", "sed"), ("cfg3disk", "sed"), ("cfg3multi", "sed"), ("cfg3flat", "sed"), ("cfg3off", "sed"), ("cfg3plum", "sed"), ("cfg1rf", "rf"), ("cfg3rf", "rf"),
                         ("cfg5small", 4000 * 3.08567758e16), ("cfg5dd", "cells"), ("cfg2shell", "cells"), ("cfg2torus", "cells"), ("cfg2ring", "cells"), ("cfg1list", "cells")):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
