@@ -237,7 +237,7 @@ typedef struct pmc_scene
     /* a source system with more than one source (SourceSystem.cpp:75-107).  num_sources <= 1: `source` above is the
        only source.  num_sources > 1: sources[0..num_sources) replace it (each with its own packet_luminosity =
        L/Npp * Lv[h]/Wv[h]), and history index h is launched by source i with source_first[i] <= h < source_first[i+1]
-       (SourceSystem::_Iv for the segment's number of packets; num_sources + 1 entries).  At most 8 sources. */
+       (SourceSystem::_Iv for the segment's number of packets; num_sources + 1 entries).  At most 16 sources (and 16 instruments). */
     int32_t         num_sources;
     const pmc_source* sources;
     const uint64_t*  source_first;

@@ -1210,7 +1210,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     }
     HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_HISTORY, 0, sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(ctr + 32, 0, 4 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
-    HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(0, 0), 0, 16 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(0, 0), 0, PMC_CTR_TASKS_PER_GROUP * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(ctx->evStart, st));
     int launchBlocks = ctx->numCU * 4;  // persistent launch workgroups, as the transition kernel's
     if (const char* env = getenv("PMC_LAUNCH_BLOCKS_PER_CU")) launchBlocks = ctx->numCU * std::max(1, atoi(env));
@@ -1225,7 +1225,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             // (the radiation-field log of the group's previous generation: its size came back with the live count)
             if (int rc = rfFlush(g, ctx->pinned[PMC_MAX_GROUPS + g])) return rc;
             ctx->pinned[PMC_MAX_GROUPS + g] = 0;
-            HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(g, 0), 0, 16 * sizeof(unsigned long long), sg));  // task cursors
+            HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(g, 0), 0, PMC_CTR_TASKS_PER_GROUP * sizeof(unsigned long long), sg));  // task cursors
             HIP_TRY(hipEventRecord(ctx->evA[g], sg));
             if (D.grid_kind == PMC_GRID_OCTREE)
             {

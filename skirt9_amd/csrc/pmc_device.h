@@ -20,9 +20,9 @@
 #include "../../include/pmc.h"
 #include <stdint.h>
 
-#define PMC_MAX_INSTRUMENTS 8   // (the observers with a peel-off packet of a cycle are flagged in eight bits of the slot's mode word;
+#define PMC_MAX_INSTRUMENTS 16  // (the observers with a peel-off packet of a cycle are flagged in sixteen bits of the slot's mode word;
                                 // the per-instrument slot arrays are sized by the scene's own instrument count)
-#define PMC_MAX_CONTEXTS 8  // scene slots in constant memory (live contexts per process and device)
+#define PMC_MAX_CONTEXTS 6  // scene slots in constant memory (live contexts per process and device; 6 x sizeof(DevScene) < 64 KB)
 #define PMC_MAX_LEVEL 12
 #define PMC_STAT_CAP 48     // entries of a slot's own contribution list per instrument: DISTINCT pixels a history contributes to
                             // (FluxRecorder statistics); a multiple of 4.  A history with more distinct pixels continues its list in
@@ -114,7 +114,7 @@ struct SlotArrays
     uint32_t* rngBlock;                     // (block << 1) | have
     double* dustExt; double* dustSca;       // extinction and scattering cross section of the dust mix at the history's wavelength
     double* dustAsym;                       // and its asymmetry parameter: DustMix::indexForLambda(lambda) is looked up ONCE, at launch
-    int32_t* mode;                          // bit 5 alive, bits 8-15 observers (group leaders) with a peel-off packet this cycle
+    int32_t* mode;                          // bit 5 alive, bits 8-23 observers (group leaders) with a peel-off packet this cycle
     int32_t* nscatt;
     int32_t* pscatt;                        // numScatt of the cycle's peel-off packets (0: emission)
     int32_t* cellhint;                      // octree leaf that contains the position, or -1
@@ -164,7 +164,7 @@ struct TaskArrays
 };
 #define PMC_TASK_NONE 0xFFFFFFFFu
 
-#define PMC_MAX_SOURCES 8
+#define PMC_MAX_SOURCES 16
 // one source of the source system: spatial sampling, luminosity per packet, wavelength sampling (pmc.h pmc_source)
 struct DevSource
 {
@@ -311,15 +311,16 @@ struct RfLogArgs
 #define PMC_RF_LOG_CHUNK 4096
 #define PMC_RF_BUCKET_BITS 13  // keys per partition of the log: 2^13 doubles = 64 KB of LDS in rfReduceKernel
 
-#define PMC_NUM_COUNTERS 256
+#define PMC_NUM_COUNTERS 512
 #define PMC_CTR_HISTORY 8
 // [16..21] work of the octree walk kernels: peel-off wave-steps, lane-steps, service rounds; propagation likewise
 #define PMC_CTR_WALKWORK 16
 // per slot group g: live slots; cursors of the walk kernels over the slots of the group (k = 0: the generic / propagation
 // kernel, k = 1 + observer: the peel-off kernel of that observer)
 #define PMC_CTR_LIVE(g) (35 + 4 * (g))
-#define PMC_CTR_TASK(g, k) (128 + 16 * (g) + (k))  // k = 0: propagation walks, 1 + i: peel-off walks towards instrument i (<= 8)
-#define PMC_CTR_RFLOG(g) PMC_CTR_TASK(g, 9)        // entries of the group's radiation-field log claimed so far
+#define PMC_CTR_TASK(g, k) (256 + 32 * (g) + (k))  // k = 0: propagation walks, 1 + i: peel-off walks towards instrument i (< 16)
+#define PMC_CTR_TASKS_PER_GROUP 32
+#define PMC_CTR_RFLOG(g) PMC_CTR_TASK(g, 31)       // entries of the group's radiation-field log claimed so far
 // per slot group g: offset of the first history the group's ended slots take up this generation (endedScanKernel)
 #define PMC_CTR_HBASE(g) (120 + (g))
 #define PMC_MAX_GROUPS 4

@@ -240,7 +240,7 @@ namespace skh
         _oligoWavelengths = rd.list(*ss, "wavelengths", "wavelength", "0.55 micron");
         _sourceBias = rd.number(*ss, "sourceBias", "0.5");
         auto sources = ss->items("sources");
-        if (sources.empty() || sources.size() > 8) unsupported("a source system with " + std::to_string(sources.size()) + " sources");
+        if (sources.empty() || sources.size() > 16) unsupported("a source system with " + std::to_string(sources.size()) + " sources");
         for (const XmlElement* srcElement : sources)
         {
         const XmlElement& src = *srcElement;

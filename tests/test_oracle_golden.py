@@ -258,11 +258,11 @@ def test_specific_luminosity_normalization(tmp_path):
         assert _same_file(golden(f), str(tmp_path / f)), f
 
 
-@pytest.mark.parametrize("name", ["cfg3disk", "cfg3plum", "cfg3multi", "cfg3flat", "cfg3off"])
+@pytest.mark.parametrize("name", ["cfg3disk", "cfg3plum", "cfg3multi", "cfg3ten", "cfg3flat", "cfg3off"])
 def test_disk_and_plummer_sources(tmp_path, name):
     """launch positions drawn from a truncated exponential disk (ExpDiskGeometry.cpp:46-68: Lambert W_-1 for the radius,
     rejection on the truncations) and from a Plummer sphere (PlummerGeometry.cpp:29-33); cfg3multi: a source system of
-    three sources (SourceSystem.cpp:14-40,75-107: composite-bias launch weights, history index ranges per source); cfg3flat: SpheroidalGeometryDecorator around the Sersic source and around a
+    three sources (SourceSystem.cpp:14-40,75-107: composite-bias launch weights, history index ranges per source), cfg3ten: of ten; cfg3flat: SpheroidalGeometryDecorator around the Sersic source and around a
     Plummer dust distribution; cfg3off: OffsetGeometryDecorator around source and dust: the SED files equal the reference's byte for byte"""
     sim = Simulation(ski(name + ".ski")).setup()
     frames, _ = O.run_primary(sim, 0, sim.num_packets, O.RNG_MT19937)
