@@ -806,7 +806,9 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if ((rc = ctx->upload(T.nbrList.data(), T.nbrList.size(), &D.nbr_list))) return bail(rc);
         if ((rc = ctx->upload(T.cellExt.data(), T.cellExt.size(), &D.cell_ext))) return bail(rc);
         D.cell_slots = T.cellSlots;
-        D.lds_grid_len = 3 * T.tabn;
+        // (levels 13-15: 0.2-0.8 MB: not in LDS; the walk reads the six walls of a step from global memory)
+        D.tab_in_lds = T.lmax <= 12 ? 1 : 0;
+        D.lds_grid_len = D.tab_in_lds ? 3 * T.tabn : 0;
     }
 
     // ---- medium

@@ -4,7 +4,7 @@
 //   octree cells    CellRec[num_cells]   the hot table of the walk step (32 B per cell: density + the six wall links), cells
 //                                        in depth-first order of the tree; LeafRec[num_cells] the cold one (box code, density)
 //   octree nodes    NodeRec[num_internal] 64-byte record per non-leaf node: box code + 8 child links (descent only)
-//   coord table     double[3][2^Lmax+1]  the reference's wall coordinates per axis and dyadic index; staged in LDS
+//   coord table     double[3][2^Lmax+1]  the reference's wall coordinates per axis and dyadic index; staged in LDS (Lmax <= 12)
 //   neighbour CSR   int32                the reference's per-wall neighbour lists of every leaf, in the reference's
 //                                        order (cold: only read when a position is not strictly inside a candidate)
 //   Cartesian       double xv/yv/zv (staged in LDS), density double[num_cells]
@@ -23,7 +23,7 @@
 #define PMC_MAX_INSTRUMENTS 16  // (the observers with a peel-off packet of a cycle are flagged in sixteen bits of the slot's mode word;
                                 // the per-instrument slot arrays are sized by the scene's own instrument count)
 #define PMC_MAX_CONTEXTS 6  // scene slots in constant memory (live contexts per process and device; 6 x sizeof(DevScene) < 64 KB)
-#define PMC_MAX_LEVEL 12
+#define PMC_MAX_LEVEL 15     // (box codes hold 20-bit byte offsets into the coordinate table: 24 x 2^15 bytes; size exponents 4 bits)
 #define PMC_STAT_CAP 48     // entries of a slot's own contribution list per instrument: DISTINCT pixels a history contributes to
                             // (FluxRecorder statistics); a multiple of 4.  A history with more distinct pixels continues its list in
                             // chained blocks of PMC_STAT_CAP entries from the slot group's pool (DevScene::stat_pool_*): the
@@ -205,6 +205,8 @@ struct DevScene
     double  fine_scale[3];       // octree: 2^lmax / extent per axis (position -> finest-level cell index)
     uint32_t tab_stride_bytes;   // octree: bytes per axis of the coordinate table = 8 * ((1 << lmax) + 1)
     const double* coord_tab;     // [3][(1<<lmax)+1]
+    int32_t tab_in_lds;          // octree: the walk kernels stage the coordinate table in LDS (lmax <= 12: up to 98 KB); deeper octrees
+                                 // read it from global memory
     int32_t coarse_level;        // octree: level Lc = min(lmax, 6) of the top-down search table
     const uint32_t* coarse_tab;  // [2^Lc][2^Lc][2^Lc] (z, y, x): link of the node at level <= Lc that covers the coarse cell
     const LeafRec* leaves;

@@ -41,7 +41,7 @@ def _rays(sim, n, seed, scale):
 
 
 @pytest.mark.parametrize("name,scale", [("cfg1.ski", 3.0857e16), ("cfg1mesh.ski", 3.0857e16), ("cfg1mesh2.ski", 3.0857e16), ("cfg2small.ski", 4000 * 3.0857e16), ("cfg4small.ski", 4000 * 3.0857e16), ("cfg5small.ski", 4000 * 3.0857e16),
-                                        ("cfg2deep.ski", 300 * 3.0857e16)])
+                                        ("cfg2deep.ski", 300 * 3.0857e16), ("cfg2deeper.ski", 100 * 3.0857e16)])
 def test_trace_ray_bit_exact(name, scale):
     sim = Simulation(ski(name)).setup()
     eng = _engine(sim)
@@ -83,7 +83,7 @@ def _compare_frames(sim, gpu, ref, n):
             assert a[:lay.num_lambda].sum() == n
 
 
-@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg2nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg3file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg3ten.ski", 20000), ("cfg3twelve.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000), ("cfg2deep.ski", 20000)])
+@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg2nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg3file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg3ten.ski", 20000), ("cfg3twelve.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000), ("cfg2deep.ski", 20000), ("cfg2deeper.ski", 20000)])
 def test_photon_loop_matches_oracle(name, n):
     sim = Simulation(ski(name), num_packets=n).setup()
     eng = _engine(sim)
@@ -108,6 +108,11 @@ def test_deep_octree_uses_the_wide_kernels():
     g = scene_head(sim).grid
     levels = np.ctypeslib.as_array(g.node_level, (g.num_nodes,))
     assert levels.max() == 12
+    # cfg2deeper.ski reaches level 14: the coordinate table (3 x 16385 doubles) does not fit in LDS, the walk kernels read the walls
+    # of a step from global memory (TreePolicy allows maxLevel up to 99; the engine's box codes hold levels up to 15)
+    sim = Simulation(ski("cfg2deeper.ski")).setup()
+    g = scene_head(sim).grid
+    assert np.ctypeslib.as_array(g.node_level, (g.num_nodes,)).max() == 14
 
 
 def test_eight_observers_and_three_slot_groups():

@@ -22,7 +22,7 @@ def _same_file(path_a, path_b):
     return a == b
 
 
-@pytest.mark.parametrize("name,nfiles", [("cfg1", 11), ("cfg1mesh", 11), ("cfg1mesh2", 11), ("cfg2small", 11), ("cfg2deep", 11), ("cfg3small", 27), ("cfg3z", 35), ("cfg1nf", 12), ("cfg2nf", 11), ("cfg4small", 11), ("cfg1file", 11), ("cfg1sed", 14), ("cfg3sed", 27)])
+@pytest.mark.parametrize("name,nfiles", [("cfg1", 11), ("cfg1mesh", 11), ("cfg1mesh2", 11), ("cfg2small", 11), ("cfg2deep", 11), ("cfg2deeper", 11), ("cfg3small", 27), ("cfg3z", 35), ("cfg1nf", 12), ("cfg2nf", 11), ("cfg4small", 11), ("cfg1file", 11), ("cfg1sed", 14), ("cfg3sed", 27)])
 def test_byte_identical_to_reference(name, nfiles, tmp_path):
     """cfg3small: panchromatic sampling with a wavelength bias, tabulated dust, 20 wavelength bins, and three
     instruments (scattering levels, a FrameInstrument sharing its observer, a second observer); cfg1nf: non-forced
@@ -40,7 +40,7 @@ def test_byte_identical_to_reference(name, nfiles, tmp_path):
         assert _same_file(golden(f), str(tmp_path / f)), f"{f} differs from the reference output"
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg1mesh", "cfg1mesh2", "cfg2small", "cfg2deep", "cfg4small", "cfg5small"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg1mesh", "cfg1mesh2", "cfg2small", "cfg2deep", "cfg2deeper", "cfg4small", "cfg5small"])
 def test_ray_segments_bit_exact(name):
     """PathSegmentGenerator (m, ds) sequences dumped from the reference (skirt_ref rays) vs the oracle's generators"""
     sim = Simulation(ski(name + ".ski")).setup()
