@@ -655,8 +655,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if ((rc = ctx->upload(scene->medium.number_density, g.num_cells, &D.cell_density))) return bail(rc);
         D.lds_grid_len = (g.nx + 1) + (g.ny + 1) + (g.nz + 1);
         D.lmax = 0;
-        if (g.nx > 1024 || g.ny > 1024 || g.nz > 1024)
-            return bail(fail(PMC_ERR_UNSUPPORTED, "Cartesian grids with more than 1024 cells per axis are not supported"));
+        if (int64_t(g.nx) * g.ny * g.nz != int64_t(g.num_cells)) return bail(fail(PMC_ERR_INVALID, "Cartesian grid: cell count does not match the border arrays"));
     }
     else if (g.kind == PMC_GRID_VORONOI)
     {

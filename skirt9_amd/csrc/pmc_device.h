@@ -155,7 +155,7 @@ struct TaskArrays
     uint32_t* bits;                         // mode (bits 0-1) | exit axis (2-3) | direction signs (4-6) | size exponent (8-11)
                                             // (octree peel-off records hold position, ds, target, sext, cell, pidx, bits only:
                                             // their direction is the observer's)
-    int32_t* cijk;                          // Cartesian: cell indices i | j << 10 | k << 20; Voronoi: exit neighbour
+    int32_t* cijk;                          // Voronoi: the neighbour (or wall) through which the path leaves the first cell
     uint64_t* pidx;                         // octree: packed fine lower-corner indices of the first cell (Walk::P)
     uint32_t* endedCount;                   // [num_slots / 64 + pad] per wave tile (64 consecutive slots): the histories that
                                             // ended in the tile this generation (transition kernel); endedScanKernel turns the

@@ -524,7 +524,9 @@ namespace skh
             grid->nx = bins("meshX");
             grid->ny = bins("meshY");
             grid->nz = bins("meshZ");
-            if (grid->nx > 1023 || grid->ny > 1023 || grid->nz > 1023) unsupported("a Cartesian grid with more than 1023 bins per axis");
+            // (the engine stages the three border arrays in LDS: 160 KB hold about 20 000 borders; the cell index is an int32)
+            if (grid->nx + grid->ny + grid->nz > 20000 || double(grid->nx) * grid->ny * grid->nz >= 2147483648.)
+                unsupported("a Cartesian grid with more than 20000 bins on its three axes together, or 2^31 cells");
             _grid = std::move(grid);
         }
         else if (ge->name == "PolicyTreeSpatialGrid")

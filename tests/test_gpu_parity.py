@@ -40,7 +40,7 @@ def _rays(sim, n, seed, scale):
     return rays
 
 
-@pytest.mark.parametrize("name,scale", [("cfg1.ski", 3.0857e16), ("cfg1mesh.ski", 3.0857e16), ("cfg1mesh2.ski", 3.0857e16), ("cfg2small.ski", 4000 * 3.0857e16), ("cfg4small.ski", 4000 * 3.0857e16), ("cfg5small.ski", 4000 * 3.0857e16),
+@pytest.mark.parametrize("name,scale", [("cfg1.ski", 3.0857e16), ("cfg1mesh.ski", 3.0857e16), ("cfg1mesh2.ski", 3.0857e16), ("cfg1long.ski", 3.0857e16), ("cfg2small.ski", 4000 * 3.0857e16), ("cfg4small.ski", 4000 * 3.0857e16), ("cfg5small.ski", 4000 * 3.0857e16),
                                         ("cfg2deep.ski", 300 * 3.0857e16), ("cfg2deeper.ski", 100 * 3.0857e16)])
 def test_trace_ray_bit_exact(name, scale):
     sim = Simulation(ski(name)).setup()
@@ -83,7 +83,7 @@ def _compare_frames(sim, gpu, ref, n):
             assert a[:lay.num_lambda].sum() == n
 
 
-@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg2nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg3file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg3ten.ski", 20000), ("cfg3twelve.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000), ("cfg2deep.ski", 20000), ("cfg2deeper.ski", 20000)])
+@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg2nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg3file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg3ten.ski", 20000), ("cfg3twelve.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg1long.ski", 5000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000), ("cfg2deep.ski", 20000), ("cfg2deeper.ski", 20000)])
 def test_photon_loop_matches_oracle(name, n):
     sim = Simulation(ski(name), num_packets=n).setup()
     eng = _engine(sim)
