@@ -96,10 +96,14 @@
     #define PMC_PEEL_QCAP 128  // task records per wave queue of the peel-off kernel (a power of two >= 128: refilled 64 at a time)
 #endif
 #ifndef PMC_PROP_TRIM
-    #define PMC_PROP_TRIM 4  // segments of a pass-1 walk recorded in LDS (pmc_walk_tree.inc walkPropKernel)
+    #define PMC_PROP_TRIM 5  // segments of a pass-1 walk recorded in LDS (pmc_walk_tree.inc walkPropKernel): what fits next to the coordinate
+                             // table of a 10-level octree in the LDS of a CU (24.6 + 768 x 172 B = 156.7 KB)
 #endif
 #ifndef PMC_PROP_BLOCK
-    #define PMC_PROP_BLOCK 256  // lanes per workgroup of the propagation kernel
+    #define PMC_PROP_BLOCK 768  // lanes per workgroup of the propagation kernel: ONE workgroup of twelve waves per CU -- three per SIMD, what
+                                // the kernel's 157 registers allow -- sharing one coordinate table.  With the slot groups overlapped, 1e8
+                                // packets: 256 lanes (one to three workgroups per CU) 624-626 ms, 512: 645, 768: 602-608, 1024: 638-642
+                                // (profiles/sweeps/r03_batch25_sweep.txt, r03_batch26_sweep.txt)
 #endif
 #ifndef PMC_PROP_MIN_WAVES
     #define PMC_PROP_MIN_WAVES 3  // likewise for the propagation kernel (<= 168 VGPRs; it uses 135-143)
