@@ -517,7 +517,7 @@ namespace
         std::memset(&K, 0, sizeof(K));
         // task records: the propagation walk + one peel-off walk per instrument, per slot
         const size_t nt = size_t(n) * size_t(1 + ctx->dev.num_instruments);
-        double** tdbl[] = {&K.rx, &K.ry, &K.rz, &K.kx, &K.ky, &K.kz, &K.ikx, &K.iky, &K.ikz, &K.s0, &K.ds, &K.target, &K.sext};
+        double** tdbl[] = {&K.rx, &K.ry, &K.rz, &K.kx, &K.ky, &K.kz, &K.s0, &K.ds, &K.target};
         for (double** d : tdbl)
             if ((rc = ctx->allocate<double>(nt, d, false, &own))) return rc;
         int32_t** tints[] = {&K.cell, &K.cijk};

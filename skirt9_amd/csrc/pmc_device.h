@@ -146,11 +146,9 @@ struct TaskArrays
 {
     double* rx; double* ry; double* rz;     // position inside the grid (after moveInside)
     double* kx; double* ky; double* kz;     // direction
-    double* ikx; double* iky; double* ikz;  // RN(1/k), NaN for an ignored axis
     double* s0;                             // length of the initial segment outside the grid (0 if none)
     double* ds;                             // exit distance of the first cell
     double* target;                         // the walk stops in the first segment with tau > target
-    double* sext;                           // extinction cross section at the packet's wavelength
     int32_t* cell;                          // first cell
     uint32_t* bits;                         // mode (bits 0-1) | exit axis (2-3) | direction signs (4-6) | size exponent (8-11)
                                             // (octree peel-off records hold position, ds, target, sext, cell, pidx, bits only:
