@@ -133,7 +133,7 @@
     #define PMC_VORO_CULL_ROUND 6  // Voronoi walk: neighbours per round of the masked exit search
 #endif
 #ifndef PMC_WALK_STEPS
-    #define PMC_WALK_STEPS 4  // steps between two service checks
+    #define PMC_WALK_STEPS 8  // steps between two round checks (4 / 8 / 16 with 256 slots per claim: 597 / 592 / 594 ms per 1e8 packets)
 #endif
 #ifndef PMC_TRANSITION_BLOCK
     #define PMC_TRANSITION_BLOCK 256  // lanes per workgroup of the transition kernel: 256 measured 4 % faster than 512
@@ -142,7 +142,8 @@
 static_assert(PMC_TRANSITION_BLOCK <= 256 && PMC_TRANSITION_BLOCK % 64 == 0,
               "the per-wave slot lists of the transition and launch kernels are laid out for at most four waves per workgroup");
 #ifndef PMC_TASK_CHUNK
-    #define PMC_TASK_CHUNK 128  // slots a wave takes from the global cursor at a time
+    #define PMC_TASK_CHUNK 256  // slots a wave takes from the global cursor at a time (64 / 128 / 256 / 512 / 1024: 611 / 597 / 592 / 600 /
+                                // 623 ms per 1e8 packets, profiles/sweeps/r03_batch32_sweep.txt, r03_batch33_sweep.txt)
 #endif
 
 // the scene of every live context, in constant memory: all accesses are scalar loads
