@@ -32,16 +32,17 @@ extern "C" int pmcPeelBlock(void);
 extern "C" int pmcPropBlock(void);
 extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int taskBase, int numTaskRecords, int taskCounter, uint64_t seed, int grid,
                                     int block, size_t ldsBytes, hipStream_t stream);
-extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, int cursor, int obs, int grid, size_t ldsBytes,
+extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int grid, size_t ldsBytes,
                                     hipStream_t stream);
-extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, int cursor, uint64_t seed, int grid,
+extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, const int* list, int cursor, uint64_t seed, int grid,
                                     size_t ldsBytes, const RfLogArgs* rfLog, hipStream_t stream);
 extern "C" hipError_t pmcLaunchRfReduce(int slot, const uint32_t* keys, const double* vals, unsigned long long n, int numBuckets, hipStream_t stream);
 extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, int maxBlocks, size_t ldsBytes,
                                           hipStream_t stream);
 extern "C" hipError_t pmcLaunchLaunch(int slot, int slotBase, int numSlots, int group, uint64_t first, uint64_t count, uint64_t seed, int initial,
                                       int maxBlocks, size_t ldsBytes, hipStream_t stream);
-extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int maxBlocks, size_t ldsBytes, hipStream_t stream);
+extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int listCounter, int maxBlocks, size_t ldsBytes,
+                                          hipStream_t stream);
 extern "C" hipError_t pmcLaunchTrace(int slot, int gridKind, int wide, int uniform, const double r[3], const double k[3],
                                      const double* kdev, int32_t* m, double* ds, int32_t cap, int32_t* n, size_t ldsBytes,
                                      hipStream_t stream);
@@ -525,6 +526,7 @@ namespace
             if ((rc = ctx->allocate<int32_t>(nt, d, false, &own))) return rc;
         // ended-history counts per tile of 64 slots (padded: the scan reads and writes 16 bytes at a time)
         if ((rc = ctx->allocate<uint32_t>(size_t(n) / 64 + 64, &K.endedCount, true, &own))) return rc;
+        if ((rc = ctx->allocate<int32_t>(n, &K.liveList, false, &own))) return rc;
         if ((rc = ctx->allocate<uint32_t>(nt, &K.bits, false, &own))) return rc;
     if (ctx->dev.grid_kind == PMC_GRID_OCTREE && (rc = ctx->allocate<uint64_t>(nt, &K.pidx, false, &own))) return rc;
         if (ctx->planning) return PMC_OK;
@@ -1085,6 +1087,12 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     if (numSlots < G * 65536) G = 1;
     int base[PMC_MAX_GROUPS], size[PMC_MAX_GROUPS];
     bool active[PMC_MAX_GROUPS], haveWalk[PMC_MAX_GROUPS];
+    // sparse generations (the end of a segment, when no history is left to launch): the cycle start kernel compacts the live
+    // slots of the group into a list, and the walk kernels of the next generation run over the list with as many workgroups
+    // as it needs -- their time then follows the live histories, not the size of the slot pool (a third of the generations of a
+    // 1e8-packet segment run fewer than a tenth of the slots)
+    bool listBuilt[PMC_MAX_GROUPS] = {false, false, false, false};
+    const bool sparseLists = D.grid_kind == PMC_GRID_OCTREE && getenv("PMC_NO_LIVE_LISTS") == nullptr;
     {
         const int per = ((numSlots / G) + PMC_TRANSITION_ALIGN - 1) / PMC_TRANSITION_ALIGN * PMC_TRANSITION_ALIGN;
         for (int g = 0; g < G; ++g)
@@ -1234,14 +1242,19 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 // propagation kernel on the group's stream (they touch different task records and result fields)
                 hipStream_t sp = ctx->peelStream[g];
                 if (serialWalks) sp = sg;
+                const unsigned long long live = ctx->pinned[g];
+                const int* list = listBuilt[g] ? D.tasks.liveList + base[g] : nullptr;
+                const int numTasks = list ? int(live) : size[g];
+                const int peelGrid = list ? std::max(1, std::min(ctx->peelGrid, (numTasks + pmcPeelBlock() - 1) / pmcPeelBlock())) : ctx->peelGrid;
+                const int propGrid = list ? std::max(1, std::min(ctx->grid, (numTasks + pmcPropBlock() - 1) / pmcPropBlock())) : ctx->grid;
                 HIP_TRY(hipStreamWaitEvent(sp, ctx->evA[g], 0));
                 for (int i = 0; i < D.num_instruments; ++i)
                     if (!D.inst[i].same_observer)
-                        HIP_TRY(pmcLaunchPeel(ctx->slot, ctx->wide, base[g], size[g], PMC_CTR_TASK(g, 1 + i), i, ctx->peelGrid, ctx->walkLds, sp));
+                        HIP_TRY(pmcLaunchPeel(ctx->slot, ctx->wide, base[g], numTasks, list, PMC_CTR_TASK(g, 1 + i), i, peelGrid, ctx->walkLds, sp));
                 HIP_TRY(hipEventRecord(ctx->evJoin[g], sp));
                 RfLogArgs log = {ctx->rfKeys[g][0], ctx->rfVals[g][0], rfLogged ? ctx->rfCap[g] : 0ull, PMC_CTR_RFLOG(g), rfPadKey};
                 if (serialWalks) HIP_TRY(hipEventRecord(ctx->evProp[g], sg));  // (in series: the propagation kernel starts where the peel-off kernels end)
-                HIP_TRY(pmcLaunchProp(ctx->slot, ctx->wide, D.rf_store, base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->walkLds, &log, sg));
+                HIP_TRY(pmcLaunchProp(ctx->slot, ctx->wide, D.rf_store, base[g], numTasks, list, PMC_CTR_TASK(g, 0), seed, propGrid, ctx->walkLds, &log, sg));
                 if (!serialWalks) HIP_TRY(hipEventRecord(ctx->evProp[g], sg));
                 HIP_TRY(hipStreamWaitEvent(sg, ctx->evJoin[g], 0));
             }
@@ -1260,8 +1273,12 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
             HIP_TRY(pmcLaunchLaunch(ctx->slot, base[g], size[g], g, first, count, seed, 1, (size[g] + 255) / 256, ctx->launchLds, sg));
         }
-        // every live slot of the group is at the start of a cycle now: the start states of its walks
-        HIP_TRY(pmcLaunchCycleStart(ctx->slot, D.grid_kind, base[g], size[g], cycleBlocks, ctx->walkLds, sg));
+        // every live slot of the group is at the start of a cycle now: the start states of its walks (and, once the live slots
+        // of the previous generation were fewer than an eighth of the group's -- they can only have become fewer, or the launch
+        // kernel would have filled the group up --, their list for the next generation's walks)
+        const bool buildList = sparseLists && !initial && ctx->pinned[g] < (unsigned long long)(size[g] / 8);
+        HIP_TRY(pmcLaunchCycleStart(ctx->slot, D.grid_kind, base[g], size[g], buildList ? PMC_CTR_LIST(g) : -1, cycleBlocks, ctx->walkLds, sg));
+        listBuilt[g] = buildList;
         HIP_TRY(hipEventRecord(ctx->evC[g], sg));
         HIP_TRY(hipMemcpyAsync(ctx->pinned + g, ctr + PMC_CTR_LIVE(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
         if (rfLogged && !initial)

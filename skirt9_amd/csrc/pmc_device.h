@@ -155,6 +155,9 @@ struct TaskArrays
                                             // their direction is the observer's)
     int32_t* cijk;                          // Voronoi: the neighbour (or wall) through which the path leaves the first cell
     uint64_t* pidx;                         // octree: packed fine lower-corner indices of the first cell (Walk::P)
+    int32_t* liveList;                      // [num_slots] sparse generations (the end of a segment): the live slots of a slot group,
+                                            // compacted by the cycle start kernel into the group's own range of this array; the walk
+                                            // kernels of the next generation then run over the list instead of the group's slot range
     uint32_t* endedCount;                   // [num_slots / 64 + pad] per wave tile (64 consecutive slots): the histories that
                                             // ended in the tile this generation (transition kernel); endedScanKernel turns the
                                             // counts of a slot group into their exclusive prefix, from which the launch kernel
@@ -320,6 +323,7 @@ struct RfLogArgs
 #define PMC_CTR_LIVE(g) (35 + 4 * (g))
 #define PMC_CTR_TASK(g, k) (256 + 32 * (g) + (k))  // k = 0: propagation walks, 1 + i: peel-off walks towards instrument i (< 16)
 #define PMC_CTR_TASKS_PER_GROUP 32
+#define PMC_CTR_LIST(g) PMC_CTR_TASK(g, 30)        // entries of the group's list of live slots (TaskArrays::liveList)
 #define PMC_CTR_RFLOG(g) PMC_CTR_TASK(g, 31)       // entries of the group's radiation-field log claimed so far
 // per slot group g: offset of the first history the group's ended slots take up this generation (endedScanKernel)
 #define PMC_CTR_HBASE(g) (120 + (g))

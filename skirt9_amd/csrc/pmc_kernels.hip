@@ -342,7 +342,7 @@ extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int tas
 }
 
 // octree: the peel-off walks towards observer `obs` of the slots [slotBase, slotBase + numSlots)
-extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, int cursor, int obs, int grid, size_t ldsBytes,
+extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int grid, size_t ldsBytes,
                                     hipStream_t stream)
 {
     static const bool first = getenv("PMC_PEEL_V1") != nullptr;  // (tuning aid: the form with service rounds)
@@ -350,7 +350,7 @@ extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlo
     if (first || ((ldsBytes + 15) & ~size_t(15)) + pmcPeelQueueBytes() > size_t(160) * 1024)
     {
         auto kernel = wide ? walkPeelKernel<true> : walkPeelKernel<false>;
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PEEL_BLOCK), ldsBytes, stream, slot, slotBase, numSlots, cursor, obs);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PEEL_BLOCK), ldsBytes, stream, slot, slotBase, numSlots, cursor, obs, list);
     }
     else
     {
@@ -358,13 +358,13 @@ extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlo
         auto kernel = wide ? walkPeelKernel2<true> : walkPeelKernel2<false>;
         const size_t queueOffset = (ldsBytes + 15) & ~size_t(15);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PEEL_BLOCK), queueOffset + pmcPeelQueueBytes(), stream, slot, slotBase, numSlots, cursor, obs,
-                           (int)queueOffset);
+                           (int)queueOffset, list);
     }
     return hipGetLastError();
 }
 
 // octree: the propagation walks of the slots [slotBase, slotBase + numSlots)
-extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, int cursor, uint64_t seed, int grid,
+extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, const int* list, int cursor, uint64_t seed, int grid,
                                     size_t ldsBytes, const RfLogArgs* rfLog, hipStream_t stream)
 {
     auto kernel = wide ? (storeRf ? walkPropKernel<true, true> : walkPropKernel<true, false>)
@@ -375,7 +375,7 @@ extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBas
     const bool trim = !noTrim && trimOffset + PROP_TRIM_BYTES <= size_t(160) * 1024;
     RfLogArgs none = {nullptr, nullptr, 0ull, 0, 0u};
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PROP_BLOCK), trim ? trimOffset + PROP_TRIM_BYTES : ldsBytes, stream, slot, slotBase, numSlots, cursor,
-                       seed, trim ? (int)trimOffset : -1, rfLog ? *rfLog : none);
+                       seed, trim ? (int)trimOffset : -1, rfLog ? *rfLog : none, list);
     return hipGetLastError();
 }
 
@@ -419,15 +419,16 @@ extern "C" hipError_t pmcLaunchLaunch(int slot, int slotBase, int numSlots, int 
 }
 
 // the walks of the cycle that every live slot of the group is about to start (task records)
-extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int maxBlocks, size_t ldsBytes, hipStream_t stream)
+extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int listCounter, int maxBlocks, size_t ldsBytes,
+                                          hipStream_t stream)
 {
     const int grid = std::max(1, std::min((numSlots + 255) / 256, maxBlocks));
     if (gridKind == PMC_GRID_OCTREE)
-        hipLaunchKernelGGL(cycleStartKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots);
+        hipLaunchKernelGGL(cycleStartKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter);
     else if (gridKind == PMC_GRID_VORONOI)
-        hipLaunchKernelGGL(cycleStartKernel<GRID_VORO>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots);
+        hipLaunchKernelGGL(cycleStartKernel<GRID_VORO>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter);
     else
-        hipLaunchKernelGGL(cycleStartKernel<GRID_CART>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots);
+        hipLaunchKernelGGL(cycleStartKernel<GRID_CART>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter);
     return hipGetLastError();
 }
 
