@@ -37,12 +37,12 @@ extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlo
 extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, const int* list, int cursor, uint64_t seed, int grid,
                                     size_t ldsBytes, const RfLogArgs* rfLog, hipStream_t stream);
 extern "C" hipError_t pmcLaunchRfReduce(int slot, const uint32_t* keys, const double* vals, unsigned long long n, int numBuckets, hipStream_t stream);
-extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, int maxBlocks, size_t ldsBytes,
-                                          hipStream_t stream);
+extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, const int* list, int listLen, int maxBlocks,
+                                          size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchLaunch(int slot, int slotBase, int numSlots, int group, uint64_t first, uint64_t count, uint64_t seed, int initial,
                                       int maxBlocks, size_t ldsBytes, hipStream_t stream);
-extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int listCounter, int maxBlocks, size_t ldsBytes,
-                                          hipStream_t stream);
+extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int listCounter, int* listOut, const int* listIn,
+                                          int listLen, int maxBlocks, size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchTrace(int slot, int gridKind, int wide, int uniform, const double r[3], const double k[3],
                                      const double* kdev, int32_t* m, double* ds, int32_t cap, int32_t* n, size_t ldsBytes,
                                      hipStream_t stream);
@@ -526,7 +526,7 @@ namespace
             if ((rc = ctx->allocate<int32_t>(nt, d, false, &own))) return rc;
         // ended-history counts per tile of 64 slots (padded: the scan reads and writes 16 bytes at a time)
         if ((rc = ctx->allocate<uint32_t>(size_t(n) / 64 + 64, &K.endedCount, true, &own))) return rc;
-        if ((rc = ctx->allocate<int32_t>(n, &K.liveList, false, &own))) return rc;
+        if ((rc = ctx->allocate<int32_t>(2 * size_t(n), &K.liveList, false, &own))) return rc;
         if ((rc = ctx->allocate<uint32_t>(nt, &K.bits, false, &own))) return rc;
     if (ctx->dev.grid_kind == PMC_GRID_OCTREE && (rc = ctx->allocate<uint64_t>(nt, &K.pidx, false, &own))) return rc;
         if (ctx->planning) return PMC_OK;
@@ -1088,10 +1088,15 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     int base[PMC_MAX_GROUPS], size[PMC_MAX_GROUPS];
     bool active[PMC_MAX_GROUPS], haveWalk[PMC_MAX_GROUPS];
     // sparse generations (the end of a segment, when no history is left to launch): the cycle start kernel compacts the live
-    // slots of the group into a list, and the walk kernels of the next generation run over the list with as many workgroups
-    // as it needs -- their time then follows the live histories, not the size of the slot pool (a third of the generations of a
-    // 1e8-packet segment run fewer than a tenth of the slots)
+    // slots of the group into a list, and the kernels of the next generation run over the list with as many workgroups as it
+    // needs -- their time then follows the live histories, not the size of the slot pool (a third of the generations of a
+    // 1e8-packet segment run fewer than a tenth of the slots).  Such a generation is walks -> transition -> cycle start: the
+    // transition kernel retires the histories that end (nothing is left to launch into their slots), the cycle start kernel
+    // writes the list of the generation after it into the other half of TaskArrays::liveList.
     bool listBuilt[PMC_MAX_GROUPS] = {false, false, false, false};
+    int listHalf[PMC_MAX_GROUPS] = {0, 0, 0, 0};  // the half of liveList that holds the group's current list
+    int listTasksPerLane = 1;  // walks per lane that size the walk kernels' grids in a sparse generation
+    if (const char* env = getenv("PMC_LIST_TASKS_PER_LANE")) listTasksPerLane = std::max(1, atoi(env));
     const bool sparseLists = D.grid_kind == PMC_GRID_OCTREE && getenv("PMC_NO_LIVE_LISTS") == nullptr;
     {
         const int per = ((numSlots / G) + PMC_TRANSITION_ALIGN - 1) / PMC_TRANSITION_ALIGN * PMC_TRANSITION_ALIGN;
@@ -1229,6 +1234,9 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     if (const char* env = getenv("PMC_TRANSITION_BLOCKS_PER_CU")) transitionBlocks = ctx->numCU * std::max(1, atoi(env));
     auto enqueue = [&](int g, bool initial) -> int {
         hipStream_t sg = ctx->groupStream[g];
+        // the list of live slots the previous generation left (as many as its live count, which came back with the stream)
+        int* const listIn = (!initial && listBuilt[g]) ? D.tasks.liveList + int64_t(listHalf[g]) * D.slots.num_slots + base[g] : nullptr;
+        const int listLen = listIn ? int(ctx->pinned[g]) : 0;
         if (!initial)
         {
             // (the radiation-field log of the group's previous generation: its size came back with the live count)
@@ -1242,11 +1250,11 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 // propagation kernel on the group's stream (they touch different task records and result fields)
                 hipStream_t sp = ctx->peelStream[g];
                 if (serialWalks) sp = sg;
-                const unsigned long long live = ctx->pinned[g];
-                const int* list = listBuilt[g] ? D.tasks.liveList + base[g] : nullptr;
-                const int numTasks = list ? int(live) : size[g];
-                const int peelGrid = list ? std::max(1, std::min(ctx->peelGrid, (numTasks + pmcPeelBlock() - 1) / pmcPeelBlock())) : ctx->peelGrid;
-                const int propGrid = list ? std::max(1, std::min(ctx->grid, (numTasks + pmcPropBlock() - 1) / pmcPropBlock())) : ctx->grid;
+                const int* list = listIn;
+                const int numTasks = list ? listLen : size[g];
+                const int peelLanes = pmcPeelBlock() * listTasksPerLane, propLanes = pmcPropBlock() * listTasksPerLane;
+                const int peelGrid = list ? std::max(1, std::min(ctx->peelGrid, (numTasks + peelLanes - 1) / peelLanes)) : ctx->peelGrid;
+                const int propGrid = list ? std::max(1, std::min(ctx->grid, (numTasks + propLanes - 1) / propLanes)) : ctx->grid;
                 HIP_TRY(hipStreamWaitEvent(sp, ctx->evA[g], 0));
                 for (int i = 0; i < D.num_instruments; ++i)
                     if (!D.inst[i].same_observer)
@@ -1264,8 +1272,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             haveWalk[g] = true;
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_LIVE(g), 0, sizeof(unsigned long long), sg));
-            HIP_TRY(pmcLaunchTransition(ctx->slot, base[g], size[g], g, seed, transitionBlocks, ctx->transitionLds, sg));
-            HIP_TRY(pmcLaunchLaunch(ctx->slot, base[g], size[g], g, first, count, seed, 0, launchBlocks, ctx->launchLds, sg));
+            HIP_TRY(pmcLaunchTransition(ctx->slot, base[g], size[g], g, seed, listIn, listLen, transitionBlocks, ctx->transitionLds, sg));
+            if (!listIn) HIP_TRY(pmcLaunchLaunch(ctx->slot, base[g], size[g], g, first, count, seed, 0, launchBlocks, ctx->launchLds, sg));
         }
         else
         {
@@ -1273,11 +1281,15 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
             HIP_TRY(pmcLaunchLaunch(ctx->slot, base[g], size[g], g, first, count, seed, 1, (size[g] + 255) / 256, ctx->launchLds, sg));
         }
-        // every live slot of the group is at the start of a cycle now: the start states of its walks (and, once the live slots
-        // of the previous generation were fewer than an eighth of the group's -- they can only have become fewer, or the launch
-        // kernel would have filled the group up --, their list for the next generation's walks)
-        const bool buildList = sparseLists && !initial && ctx->pinned[g] < (unsigned long long)(size[g] / 8);
-        HIP_TRY(pmcLaunchCycleStart(ctx->slot, D.grid_kind, base[g], size[g], buildList ? PMC_CTR_LIST(g) : -1, cycleBlocks, ctx->walkLds, sg));
+        // every live slot of the group is at the start of a cycle now: the start states of its walks -- and, once the live slots
+        // of the previous generation were fewer than half of the group's, their list for the next generation.  (The launch kernel
+        // fills every slot whose history has ended as long as SourceSystem has an index left: fewer live slots than slots means
+        // that nothing is left to launch, and the live slots can only become fewer.)
+        const bool buildList = sparseLists && !initial && (listIn || ctx->pinned[g] < (unsigned long long)(size[g] / 2));
+        if (listIn) listHalf[g] ^= 1;
+        int* const listOut = D.tasks.liveList + int64_t(listHalf[g]) * D.slots.num_slots + base[g];
+        HIP_TRY(pmcLaunchCycleStart(ctx->slot, D.grid_kind, base[g], size[g], buildList ? PMC_CTR_LIST(g) : -1, listOut, listIn, listLen, cycleBlocks,
+                                    ctx->walkLds, sg));
         listBuilt[g] = buildList;
         HIP_TRY(hipEventRecord(ctx->evC[g], sg));
         HIP_TRY(hipMemcpyAsync(ctx->pinned + g, ctr + PMC_CTR_LIVE(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));

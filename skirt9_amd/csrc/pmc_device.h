@@ -155,9 +155,10 @@ struct TaskArrays
                                             // their direction is the observer's)
     int32_t* cijk;                          // Voronoi: the neighbour (or wall) through which the path leaves the first cell
     uint64_t* pidx;                         // octree: packed fine lower-corner indices of the first cell (Walk::P)
-    int32_t* liveList;                      // [num_slots] sparse generations (the end of a segment): the live slots of a slot group,
-                                            // compacted by the cycle start kernel into the group's own range of this array; the walk
-                                            // kernels of the next generation then run over the list instead of the group's slot range
+    int32_t* liveList;                      // [2][num_slots] sparse generations (the end of a segment): the live slots of a slot group,
+                                            // compacted by the cycle start kernel into the group's own range of one half of this array;
+                                            // the kernels of the next generation run over the list instead of the group's slot range
+                                            // (and write the list of the generation after it into the other half)
     uint32_t* endedCount;                   // [num_slots / 64 + pad] per wave tile (64 consecutive slots): the histories that
                                             // ended in the tile this generation (transition kernel); endedScanKernel turns the
                                             // counts of a slot group into their exclusive prefix, from which the launch kernel

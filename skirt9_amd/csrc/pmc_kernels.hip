@@ -397,14 +397,15 @@ extern "C" hipError_t pmcLaunchStatMerge(int slot, int blocks, hipStream_t strea
 
 // transitions of the slots [slotBase, slotBase + numSlots) of slot group `group`, followed by the scan of the group's
 // ended-history counts (the launch kernel's history indices)
-extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, int maxBlocks, size_t ldsBytes,
-                                          hipStream_t stream)
+extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, const int* list, int listLen, int maxBlocks,
+                                          size_t ldsBytes, hipStream_t stream)
 {
     const int block = PMC_TRANSITION_BLOCK;
-    const int grid = std::max(1, std::min((numSlots + block - 1) / block, maxBlocks));
-    hipLaunchKernelGGL(transitionKernel, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group, seed);
+    // (a sparse generation: one list entry per lane; otherwise persistent workgroups over runs of 256 slots per wave)
+    const int grid = std::max(1, std::min(((list ? listLen : numSlots) + block - 1) / block, maxBlocks));
+    hipLaunchKernelGGL(transitionKernel, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group, seed, list, listLen);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || list) return e;  // (a sparse generation retires its ended histories in the transition kernel)
     hipLaunchKernelGGL(endedScanKernel, dim3(1), dim3(1024), 0, stream, slot, slotBase, numSlots, group);
     return hipGetLastError();
 }
@@ -419,16 +420,16 @@ extern "C" hipError_t pmcLaunchLaunch(int slot, int slotBase, int numSlots, int 
 }
 
 // the walks of the cycle that every live slot of the group is about to start (task records)
-extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int listCounter, int maxBlocks, size_t ldsBytes,
-                                          hipStream_t stream)
+extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int listCounter, int* listOut, const int* listIn,
+                                          int listLen, int maxBlocks, size_t ldsBytes, hipStream_t stream)
 {
-    const int grid = std::max(1, std::min((numSlots + 255) / 256, maxBlocks));
+    const int grid = std::max(1, std::min(((listIn ? listLen : numSlots) + 255) / 256, maxBlocks));
     if (gridKind == PMC_GRID_OCTREE)
-        hipLaunchKernelGGL(cycleStartKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter);
+        hipLaunchKernelGGL(cycleStartKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter, listOut, listIn, listLen);
     else if (gridKind == PMC_GRID_VORONOI)
-        hipLaunchKernelGGL(cycleStartKernel<GRID_VORO>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter);
+        hipLaunchKernelGGL(cycleStartKernel<GRID_VORO>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter, listOut, listIn, listLen);
     else
-        hipLaunchKernelGGL(cycleStartKernel<GRID_CART>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter);
+        hipLaunchKernelGGL(cycleStartKernel<GRID_CART>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter, listOut, listIn, listLen);
     return hipGetLastError();
 }
 
