@@ -165,6 +165,10 @@ struct TaskArrays
                                             // derives the index of the history each of those slots takes up next
 };
 #define PMC_TASK_NONE 0xFFFFFFFFu
+#define PMC_TASK_MOVED 0x1000u  // octree: bit 12 of TaskArrays::bits: PathSegmentGenerator::moveInside has moved the start of the walk (the
+                                // position was outside the grid): position and initial path length are in the record; otherwise the
+                                // walk starts at the slot's position (SlotArrays::rx ...) with no initial length, and the record holds
+                                // neither (nor, ever, the direction of a propagation walk: it is the slot's)
 
 #define PMC_MAX_SOURCES 16
 // one source of the source system: spatial sampling, luminosity per packet, wavelength sampling (pmc.h pmc_source)
