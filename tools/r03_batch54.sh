@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 3, batch 54 (GPU box): no pscatt array, no stop value in forced pass-1 records -- parity tests, A/B
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out/r03_batch54; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; grep -E "passed|failed" $O/pytest.log | tail -2
+python tools/sweep.py --packets 1e8 libpmc_prev.so default libpmc_prev.so default libpmc_prev.so default > $O/sweep.txt 2>&1; grep "pkt/s" $O/sweep.txt
+python tools/sweep.py --packets 1e7 libpmc_prev.so default libpmc_prev.so default > $O/sweep1e7.txt 2>&1; grep "pkt/s" $O/sweep1e7.txt
