@@ -478,7 +478,7 @@ namespace
             if ((rc = ctx->allocate<double>(n, d, false, &own))) return rc;
         if ((rc = ctx->allocate<uint64_t>(n, &A.history, false, &own))) return rc;
         if ((rc = ctx->allocate<uint32_t>(n, &A.rngBlock, false, &own))) return rc;
-        int32_t** ints[] = {&A.mode, &A.nscatt, &A.pscatt, &A.cellhint, &A.mint};
+        int32_t** ints[] = {&A.mode, &A.nscatt, &A.cellhint, &A.mint};
         for (int32_t** d : ints)
             if ((rc = ctx->allocate<int32_t>(n, d, true, &own))) return rc;
         if ((rc = ctx->allocate<double>(size_t(n) * size_t(ctx->dev.num_instruments), &A.ppW, false, &own))) return rc;

@@ -116,7 +116,6 @@ struct SlotArrays
     double* dustAsym;                       // and its asymmetry parameter: DustMix::indexForLambda(lambda) is looked up ONCE, at launch
     int32_t* mode;                          // bit 5 alive, bits 8-23 observers (group leaders) with a peel-off packet this cycle
     int32_t* nscatt;
-    int32_t* pscatt;                        // numScatt of the cycle's peel-off packets (0: emission)
     int32_t* cellhint;                      // octree leaf that contains the position, or -1
     int32_t* ell;                           // [num_instruments][num_slots] wavelength bin per instrument
     int32_t* statHead;                      // [num_instruments][num_slots] 64-byte head record of the history's contribution list:
