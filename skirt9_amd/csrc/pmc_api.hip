@@ -478,7 +478,7 @@ namespace
             if ((rc = ctx->allocate<double>(n, d, false, &own))) return rc;
         if ((rc = ctx->allocate<uint64_t>(n, &A.history, false, &own))) return rc;
         if ((rc = ctx->allocate<uint32_t>(n, &A.rngBlock, false, &own))) return rc;
-        int32_t** ints[] = {&A.mode, &A.nscatt, &A.cellhint, &A.mint};
+        int32_t** ints[] = {&A.mode, &A.nscatt, &A.mint};
         for (int32_t** d : ints)
             if ((rc = ctx->allocate<int32_t>(n, d, true, &own))) return rc;
         if ((rc = ctx->allocate<double>(size_t(n) * size_t(ctx->dev.num_instruments), &A.ppW, false, &own))) return rc;
@@ -884,6 +884,33 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     D.src_first[numSources] = numSources > 1 ? scene->source_first[numSources] : ~0ull;
     for (int si = 1; si < numSources; ++si)
         if (D.src[si].lambda_mode != D.src[0].lambda_mode) return bail(fail(PMC_ERR_INVALID, "sources with different wavelength regimes"));
+    // one wavelength for every history: its dust properties are found here once, as launchHistory finds them (DustMix::indexForLambda:
+    // NR::locateClip on the index borders)
+    auto sourceOf = [&](int si) -> const pmc_source& { return numSources > 1 ? scene->sources[si] : scene->source; };
+    D.mono = (sourceOf(0).lambda_mode == PMC_LAMBDA_OLIGO && getenv("PMC_NO_MONO") == nullptr) ? 1 : 0;
+    for (int si = 0; si < numSources && D.mono; ++si)
+        if (sourceOf(si).num_oligo != 1 || sourceOf(si).oligo_lambda[0] != sourceOf(0).oligo_lambda[0]) D.mono = 0;
+    D.mono_lambda = D.mono_ext = D.mono_sca = D.mono_asym = 0.;
+    if (D.mono)
+    {
+        const double lambda = sourceOf(0).oligo_lambda[0];
+        int il = 0;
+        if (!(lambda < med.lambda_border[0]))
+        {
+            int jl = -1, ju = med.num_lambda - 1;
+            while (ju - jl > 1)
+            {
+                const int jm = (ju + jl) >> 1;
+                if (lambda < med.lambda_border[jm])
+                    ju = jm;
+                else
+                    jl = jm;
+            }
+            il = jl;
+        }
+        D.mono_lambda = lambda;
+        D.mono_ext = med.sigma_ext[il], D.mono_sca = med.sigma_sca[il], D.mono_asym = med.asymmpar[il];
+    }
 
     // ---- instruments and frame layout
     D.num_instruments = scene->num_instruments;

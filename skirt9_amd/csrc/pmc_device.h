@@ -116,7 +116,6 @@ struct SlotArrays
     double* dustAsym;                       // and its asymmetry parameter: DustMix::indexForLambda(lambda) is looked up ONCE, at launch
     int32_t* mode;                          // bit 5 alive, bits 8-23 observers (group leaders) with a peel-off packet this cycle
     int32_t* nscatt;
-    int32_t* cellhint;                      // octree leaf that contains the position, or -1
     int32_t* ell;                           // [num_instruments][num_slots] wavelength bin per instrument
     int32_t* statHead;                      // [num_instruments][num_slots] 64-byte head record of the history's contribution list:
                                             // {int32 bin[4]; double w[4]; int32 n; int32 next; 8 unused}: the first four entries, the
@@ -129,7 +128,9 @@ struct SlotArrays
                                             // contribution is zero)
     double* sint;                           // propagation walk: interaction distance
     double* nint;                           //         density of the interaction cell
-    int32_t* mint;                          //         interaction cell (-1: no interaction, the history ends)
+    int32_t* mint;                          //         interaction cell (-1: no interaction, the history ends); after the scattering
+                                            //         there it is the leaf that contains the slot's position: the hint for the first cell
+                                            //         of the next cycle's walks (the launch kernel stores -1: no hint)
     // per-history contribution lists, entries 4 .. PMC_STAT_CAP - 1: bin[(inst * num_slots + slot) * PMC_STAT_CAP + e], w likewise
     int32_t* statBin;
     double*  statW;
@@ -248,6 +249,11 @@ struct DevScene
     const double* sigma_ext;
     const double* sigma_sca;
     const double* asymmpar;
+    // every source emits at ONE wavelength, the same one (oligochromatic with a single wavelength: BASELINE configs[0] and [1]): the
+    // wavelength of a history and the dust mix's properties at it are constants of the scene, and no kernel stores or loads them per
+    // slot (SlotArrays::lambda, dustExt, dustSca, dustAsym stay unused)
+    int32_t mono;
+    double mono_lambda, mono_ext, mono_sca, mono_asym;
     // ---- options
     int32_t force_scattering;
     double  min_weight_reduction;
