@@ -946,6 +946,22 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         d.num_border = I.num_border;
         if ((rc = ctx->upload(I.border, I.num_border, &d.border))) return bail(rc);
         if ((rc = ctx->upload(I.ellv, I.num_border + 1, &d.ellv))) return bail(rc);
+        d.mono_ell = -1;
+        if (D.mono)
+        {
+            // (DisjointWavelengthGrid::bin of the redshifted wavelength, as launchHistory finds it: upper_bound on the borders)
+            const double lambdaObs = D.mono_lambda * d.zp1;
+            int lo = 0, hi = I.num_border;
+            while (lo < hi)
+            {
+                const int mid = (lo + hi) >> 1;
+                if (lambdaObs < I.border[mid])
+                    hi = mid;
+                else
+                    lo = mid + 1;
+            }
+            d.mono_ell = I.ellv[lo];
+        }
         pmc_frame_layout L;
         ctx->frameSize = pmc_layout_compute(scene, i, &L);
         d.sed_offset = L.sed_offset, d.ifu_offset = L.ifu_offset, d.wsed_offset = L.wsed_offset, d.wifu_offset = L.wifu_offset;

@@ -86,6 +86,7 @@ struct DevInstrument
     double aperture_r2;  // SEDInstrument aperture radius squared (0: none)
     double zp1;          // 1 + redshift of the observer frame: the wavelength bins are looked up at lambda (1 + z) (FluxRecorder.cpp:309-310)
     int32_t num_lambda, num_border;
+    int32_t mono_ell;       // DevScene::mono: the wavelength bin of every history in this instrument (-1: outside its grid)
     const double* border;   // device
     const int32_t* ellv;    // device
     // frame layout (doubles)
