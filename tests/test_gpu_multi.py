@@ -160,3 +160,32 @@ def test_sparse_generations_equal_the_slot_order_generations(monkeypatch):
     npix = lay.npix * lay.num_lambda
     assert np.array_equal(a[lay.wifu_offset:lay.wifu_offset + npix], b[lay.wifu_offset:lay.wifu_offset + npix])
     assert np.allclose(a, b, rtol=1e-11, atol=0)
+
+
+def test_one_wavelength_constants_equal_the_per_slot_arrays(monkeypatch):
+    """A scene whose sources all emit at one wavelength keeps that wavelength, its bin in every instrument and the dust mix's
+    properties at it as constants of the scene (pmc_api.hip `D.mono`, found as launchHistory finds them: DustMix::indexForLambda,
+    DisjointWavelengthGrid::bin); PMC_NO_MONO=1 stores and loads them per slot, as panchromatic scenes do.  Same histories, same
+    random streams: equal counters, equal numbers of contributing histories per pixel, sums equal to the order of the atomic
+    additions."""
+    from skirt9_amd.engine import Engine
+    from skirt9_amd.host import Simulation
+    n = 200000
+    for name in ("cfg1.ski", "cfg2small.ski"):
+        sim = Simulation(ski(name), num_packets=n).setup()
+        lay = sim.layout(0)
+        out = []
+        for mono in (True, False):
+            if mono:
+                monkeypatch.delenv("PMC_NO_MONO", raising=False)
+            else:
+                monkeypatch.setenv("PMC_NO_MONO", "1")
+            eng = Engine(sim.scene, 0)
+            eng.run_primary(0, n, 3)
+            out.append((eng.download(), eng.counters()))
+            eng.close()
+        (a, ca), (b, cb) = out
+        assert ca == cb and ca["histories"] == n, name
+        npix = lay.npix * lay.num_lambda
+        assert np.array_equal(a[lay.wifu_offset:lay.wifu_offset + npix], b[lay.wifu_offset:lay.wifu_offset + npix]), name
+        assert np.allclose(a, b, rtol=1e-11, atol=0), name
