@@ -14,7 +14,7 @@ PASSES=(
 i=0
 for p in "${PASSES[@]}"; do
   i=$((i+1))
-  (cd /tmp && timeout 90 rocprofv3 --pmc $p --output-format csv -d $OUT/pass$i -- python $OLDPWD/bench.py $ARGS > $OUT/pass$i.log 2>&1)
+  (cd /tmp && timeout 240 rocprofv3 --pmc $p --output-format csv -d $OUT/pass$i -- python $OLDPWD/bench.py $ARGS > $OUT/pass$i.log 2>&1)
 done
 python3 - <<'PY'
 import csv, glob, collections, os
@@ -25,7 +25,7 @@ calls = collections.defaultdict(set)
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         import re
-        m = re.search(r"(walkPeelKernel|walkPropKernel|walkKernel|transitionKernel|launchKernel|statMergeKernel|chase)", row["Kernel_Name"])
+        m = re.search(r"(walkPeelKernel|walkPropKernel|walkKernel|transitionKernel|launchKernel|cycleStartKernel|endedScanKernel|statMergeKernel|chase)", row["Kernel_Name"])
         if not m: continue
         k = m.group(1)
         tot[k][row["Counter_Name"]] += float(row["Counter_Value"])
