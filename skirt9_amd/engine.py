@@ -63,12 +63,11 @@ def lib():
         L.pmc_set_num_slots.argtypes = [C.c_void_p, C.c_int64]
         L.pmc_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                       C.POINTER(C.c_int32)]
-        if os.environ.get("PMC_LIBRARY") and not hasattr(L, "pmc_walk_work"):
-            # (kernel A/B experiments against an engine built from an older commit: tools/sweep.py copes without these)
-            _lib = L
-            return _lib
-        L.pmc_last_walk_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
-        L.pmc_walk_work.argtypes = [C.c_void_p, C.POINTER(WalkWork)]
+        if hasattr(L, "pmc_walk_work"):
+            # (absent only from engines built from an older commit and loaded through PMC_LIBRARY for kernel A/B experiments:
+            # tools/sweep.py copes without these two; every other prototype below is still set)
+            L.pmc_last_walk_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+            L.pmc_walk_work.argtypes = [C.c_void_p, C.POINTER(WalkWork)]
         L.pmc_radiation_field_size.restype = C.c_int64
         L.pmc_radiation_field_size.argtypes = [C.c_void_p]
         L.pmc_radiation_field_device.restype = C.c_void_p
@@ -240,7 +239,7 @@ class Engine:
 
     def bind_radiation_field(self, device_ptr, num_doubles):
         """accumulate the radiation field into caller-owned device memory (a zeroed float64 torch tensor), so that
-        torch.distributed can all-reduce it over RCCL (skirt9_amd.distributed.allreduce_radiation_field)"""
+        ``Engine.allreduce_radiation_field`` / pmc_allreduce_radiation_field sums it over the ranks"""
         _check(lib().pmc_bind_radiation_field(self._h, C.c_void_p(device_ptr), num_doubles))
 
     def download_radiation_field(self):

@@ -30,6 +30,9 @@ Fixtures:
                benchmark): 312 fixed rays (random, mid-plane, axis-parallel, and rays aimed at cell corners and edges) with the
                reference's (m, ds) sequences (gzip), the cell count and SHA-256 digests of the reference's per-cell volumes and
                number densities (bit patterns, cell order)
+  cfg2_i0_sed.dat, cfg2_i0_sedstats.dat, cfg2_full_rebinned.npz   the photon loop of the same full-size scene: 10^5 packets, seed 0, one
+               thread; the two SED files as written, and every FITS frame (flux components, statistics w^0 .. w^4) summed over
+               8 x 8 blocks of the 512^2 pixels in double precision (the ten 1 MB FITS files themselves are not committed)
   cfg5dd_cells.npz   the same grid with its sites drawn from the dust density (policy DustDensity): volumes, densities
   cfg4small_*  reduced config 4 (tests/ski/cfg4small.ski): dust imported from 3000 smoothed particles
                (tests/ski/cfg4small_sph.txt, made by tools/make_sph.py), 2x10^4 packets -> files, rays, cells
@@ -97,6 +100,30 @@ def rays_config2():
                     ((0.0625, 0.0625, 0.0), (s2, s2, 0.0)), ((0.0, 0.0, 0.0), (0.0, s2, -s2))):
         out.append((np.array(frac) * ext, np.array(k) / np.linalg.norm(k)))
     return out
+
+
+def read_fits(path):
+    """primary image of a FITS file written by FITSInOut::write: float32, big endian"""
+    raw = open(path, "rb").read()
+    cards = {}
+    pos = 0
+    while True:
+        card = raw[pos:pos + 80].decode("ascii")
+        pos += 80
+        if card.startswith("END"):
+            break
+        if "=" in card[:10]:
+            cards[card[:8].strip()] = card[10:].split("/")[0].strip()
+    pos = (pos + 2879) // 2880 * 2880
+    shape = [int(cards[f"NAXIS{i}"]) for i in range(int(cards["NAXIS"]), 0, -1)]
+    count = int(np.prod(shape))
+    return np.frombuffer(raw[pos:pos + 4 * count], dtype=">f4").astype(np.float64).reshape(shape)
+
+
+def rebin(a, f=8):
+    a = a.reshape(a.shape[-2], a.shape[-1])
+    ny, nx = a.shape
+    return a.reshape(ny // f, f, nx // f, f).sum(axis=(1, 3))
 
 
 def main():
@@ -186,6 +213,14 @@ def main():
         import json
         ski = os.path.join(ROOT, "tests", "ski", "cfg2.ski")
         with tempfile.TemporaryDirectory() as tmp:
+            # the photon loop at full size (27 s): SED files + the FITS frames rebinned 8 x 8
+            subprocess.check_call([REF, "run", ski, "-t", "1", "-o", tmp], cwd=tmp, stdout=subprocess.DEVNULL)
+            for f in ("cfg2_i0_sed.dat", "cfg2_i0_sedstats.dat"):
+                shutil.copy(os.path.join(tmp, f), os.path.join(HERE, f))
+            frames = {}
+            for name in ("total", "transparent", "primarydirect", "primaryscattered", "stats0", "stats1", "stats2", "stats3", "stats4"):
+                frames[name] = rebin(read_fits(os.path.join(tmp, f"cfg2_i0_{name}.fits")))
+            np.savez_compressed(os.path.join(HERE, "cfg2_full_rebinned.npz"), **frames)
             rayfile = os.path.join(HERE, "cfg2_rays.txt")
             with open(rayfile, "w") as fh:
                 for r, k in rays_config2():

@@ -201,7 +201,7 @@ def config5_simulation(tmp_dir, num_packets=1000):
             os.environ["SKH_INPUT_PATH"] = old
 
 
-def test_full_size_config2_equals_the_reference():
+def test_full_size_config2_equals_the_reference(tmp_path):
     """BASELINE configs[1] at FULL size (tests/ski/cfg2.ski, the octree the benchmark runs on): the host layer builds the
     reference's tree (953 688 cells; DensityTreePolicy.cpp:117-231, TreeSpatialGrid.cpp:34-130) with the reference's
     volumes and sampled densities -- SHA-256 of the bit patterns in cell order -- and the oracle's path generator
@@ -210,7 +210,7 @@ def test_full_size_config2_equals_the_reference():
     import hashlib
     import json
     from test_host_model import scene_head
-    sim = Simulation(ski("cfg2.ski"), num_packets=1000).setup()
+    sim = Simulation(ski("cfg2.ski")).setup()
     gold = json.load(open(golden("cfg2_cells.json")))
     g = scene_head(sim).grid
     assert g.num_cells == gold["num_cells"] == 953688
@@ -231,6 +231,20 @@ def test_full_size_config2_equals_the_reference():
         assert np.array_equal(ds.view(np.uint64), ds_ref.view(np.uint64)), (r, k)
         total += len(m_ref)
     assert total > 10000
+    # the photon loop on this scene: 1e5 histories with the reference's generator continued after the setup draws -- the SED files
+    # byte for byte, and every FITS frame (flux components, statistics) equal to the reference's in sums over 8 x 8 pixel blocks
+    # (tests/golden/cfg2_full_rebinned.npz: the float32 pixels of the reference's files summed in double precision)
+    assert sim.num_packets == 100000
+    frames, counters = O.run_primary(sim, 0, sim.num_packets, O.RNG_MT19937)
+    assert counters.histories == sim.num_packets
+    sim.write(frames, str(tmp_path))
+    for f in ("cfg2_i0_sed.dat", "cfg2_i0_sedstats.dat"):
+        assert _same_file(golden(f), str(tmp_path / f)), f
+    from test_gpu_parity import _read_fits
+    blocks = np.load(golden("cfg2_full_rebinned.npz"))
+    for name in blocks.files:
+        a = _read_fits(str(tmp_path / f"cfg2_i0_{name}.fits")).reshape(512, 512)
+        assert np.array_equal(a.reshape(64, 8, 64, 8).sum(axis=(1, 3)), blocks[name]), name
 
 
 def test_full_size_voronoi_rays_bit_exact(tmp_path):
