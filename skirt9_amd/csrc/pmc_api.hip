@@ -1488,6 +1488,17 @@ int pmc_walk_work(pmc_ctx* ctx, pmc_walk_work_values* out)
     return PMC_OK;
 }
 
+int pmc_debug_tables(pmc_ctx* ctx, pmc_debug_table_values* out)
+{
+    if (!ctx || !out) return fail(PMC_ERR_INVALID, "null argument");
+    if (ctx->dev.grid_kind != PMC_GRID_OCTREE) return fail(PMC_ERR_INVALID, "not an octree scene");
+    out->cell_table = ctx->dev.cell_tab;
+    out->cell_slots = ctx->dev.cell_slots;
+    out->task_cell = ctx->dev.tasks.cell;
+    out->num_slots = ctx->allocatedSlots;
+    return PMC_OK;
+}
+
 int pmc_download(pmc_ctx* ctx, double* host_frames, int64_t num_doubles)
 {
     if (!ctx || !host_frames) return fail(PMC_ERR_INVALID, "null argument");

@@ -21,9 +21,15 @@ SYMBOLS = ["pmc_abi_version", "pmc_last_error", "pmc_frame_layout_of", "pmc_crea
            "pmc_set_num_slots", "pmc_last_timing", "pmc_last_walk_timing", "pmc_walk_work", "pmc_radiation_field_size", "pmc_radiation_field_device",
            "pmc_download_radiation_field", "pmc_clear_radiation_field", "pmc_bind_radiation_field", "pmc_sampler_create",
            "pmc_sampler_density", "pmc_sampler_destroy", "pmc_history_range", "pmc_comm_init_all", "pmc_comm_unique_id",
-           "pmc_comm_init_rank", "pmc_comm_size", "pmc_comm_destroy", "pmc_reduce_frames", "pmc_allreduce_radiation_field"]
+           "pmc_comm_init_rank", "pmc_comm_size", "pmc_comm_destroy", "pmc_reduce_frames", "pmc_allreduce_radiation_field",
+           "pmc_debug_tables"]
 
 _lib = None
+
+
+class DebugTables(C.Structure):
+    """pmc_debug_table_values (include/pmc.h): device addresses for profiles/microbench/bridge.hip"""
+    _fields_ = [("cell_table", C.c_void_p), ("cell_slots", C.c_int64), ("task_cell", C.c_void_p), ("num_slots", C.c_int64)]
 
 
 class WalkWork(C.Structure):
@@ -213,6 +219,13 @@ class Engine:
         w = WalkWork()
         _check(lib().pmc_walk_work(self._h, C.byref(w)))
         return {n: int(getattr(w, n)) for n, _ in w._fields_}
+
+    def debug_tables(self):
+        """device addresses of the octree walk's hot table and of the task records' first cells (tuning aid)"""
+        t = DebugTables()
+        lib().pmc_debug_tables.argtypes = [C.c_void_p, C.POINTER(DebugTables)]
+        _check(lib().pmc_debug_tables(self._h, C.byref(t)))
+        return t
 
     def reduce_frames(self, comm_handle, root=0):
         """end of a segment on several devices: ONE ncclReduce (f64, sum) of the detector arrays onto `root`
