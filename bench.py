@@ -36,11 +36,15 @@ sys.path.insert(0, ROOT)
 SKI = os.path.join(ROOT, "tests", "ski", "cfg2.ski")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 VORONOI_KEPT_NEIGHBOURS = 0.60  # fraction of a Voronoi cell's neighbours the walk reads after the cone cull
-GATHER_CEILING = 2.1e11  # dependent random 32-byte gathers per second through a 32 MB table at 12-14 waves per CU (measured)
+# random dependent gathers per second of the whole chip with every lane on a trajectory of its own (profiles/microbench/
+# true_gather_mi355x.txt; the 2.1e11 of rounds 2-3 came from lanes that merged, profiles/r04_bridge.md): a 32 MB table without any
+# locality, and a table that fits the 4 MB L2 of an XCD -- the walk kernels' lane-step rates lie between the two by their locality
+GATHER_NO_LOCALITY = 0.665e11
+GATHER_L2_RESIDENT = 2.5e11
 
 
 def pmc_traffic(packets_per_step):
-    """(bytes, source file) -- HBM bytes the walk kernels move in one step (all their launches), from the newest committed PMC summary
+    """(bytes of the walk kernels, bytes of all kernels, source file) -- memory-side bytes of one step, from the newest committed PMC summary
     profiles/r*_pmc_hbm.csv: FETCH_SIZE + WRITE_SIZE (KiB, separate rocprofv3 --pmc passes over one step of 2e7
     packets of this workload; tools/run_profile_set.sh, tools/pmc_hbm_summary.py), scaled by the packet count.  The
     kernel's reads are 16-byte gathers (64-byte fabric requests), so the gfx950 x2 correction for wide coalesced
@@ -52,12 +56,14 @@ def pmc_traffic(packets_per_step):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.csv")),
                    key=lambda f: [int(x) for x in re.findall(r"[0-9]+", os.path.basename(f))])
     if not files:
-        return None, None
-    kib = 0.0
+        return None, None, None
+    kib = allkib = 0.0
     for row in csv.DictReader(open(files[-1])):
+        allkib += float(row["sum_KiB_per_step_of_2e7_packets"])
         if row["kernel"] in ("walkKernel", "walkPeelKernel", "walkPropKernel"):
             kib += float(row["sum_KiB_per_step_of_2e7_packets"])
-    return (kib * 1024.0 / 2e7 * packets_per_step if kib else None), os.path.relpath(files[-1], ROOT)
+    scale = 1024.0 / 2e7 * packets_per_step
+    return (kib * scale if kib else None), (allkib * scale if allkib else None), os.path.relpath(files[-1], ROOT)
 
 
 def cpu_baseline(ski_path=SKI, input_dir=None, packets_per_core=100000):
@@ -122,6 +128,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the second measurement of the default run (the same octree with a uniform-box source)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--secondary", action="store_true", help="N > 1: also measure the uniform-box source (default at N = 1)")
+    ap.add_argument("--no-breakdown", action="store_true", help="skip the per-kernel pass (one slot group, kernels in series) behind the timed region")
     args = ap.parse_args()
 
     import torch
@@ -225,25 +233,34 @@ def main():
         # Every rank needs a replica of the scene.  ONE rank sets it up (all host cores) and saves it as one file in /dev/shm
         # (skh_scene_save); the others load that file -- no second tree construction, no second density sampling.
         sim = None
-        cache = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir(),
-                             f"pmc_scene_{os.environ.get('MASTER_PORT', '0')}_{os.path.basename(path)}_{total_per_step}.bin")
+        cache = None
+        t_setup = time.perf_counter()
         if rank == 0:
             sim = Simulation(path, num_packets=total_per_step)
             if args.config == 4:
                 sim.use_device_sampler(local_rank)  # setup-time density sampling of the particle medium on this rank's GPU
             sim.setup()
             if world > 1:
+                # (a private file under an unpredictable name, readable by this user only; the loader checks sizes, offsets and a
+                # checksum before it trusts a byte of it)
+                fd, cache = tempfile.mkstemp(prefix="pmc_scene_", suffix=".bin", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+                os.close(fd)
+                os.chmod(cache, 0o600)
                 sim.save_scene(cache)
         if world > 1:
-            dist.barrier()
+            names = [cache]
+            dist.broadcast_object_list(names, src=0)
+            cache = names[0]
             if rank != 0:
                 sim = SceneFile(cache)
             dist.barrier()
             if rank == 0:
                 os.unlink(cache)
         eng = Engine(sim.scene, local_rank)
+        setup_s = time.perf_counter() - t_setup   # (rank 0: the whole setup; the others: waiting for it + loading the scene file)
         frames = torch.zeros(sim.frame_size, dtype=torch.float64, device=f"cuda:{local_rank}")
         eng.bind_frames(frames.data_ptr(), frames.numel())
+        reduce_ms = []
         rf = None
         if sim.radiation_field_size:
             # the radiation field table in a torch tensor, so that the ranks can sum it onto ALL ranks over RCCL
@@ -263,10 +280,12 @@ def main():
             if comm is not None:
                 # ONE ncclReduce of the bound frames onto rank 0 on the engine's stream; the other ranks' frames are cleared
                 # (pmc_reduce_frames returns when the reduce is complete)
+                t_red = time.perf_counter()
                 eng.reduce_frames(comm.handles[0], 0)
                 if rf is not None:
                     eng.allreduce_radiation_field(comm.handles[0])
                     rf.zero_()      # (a benchmark step is a whole segment: what follows would consume the field here)
+                reduce_ms.append(1e3 * (time.perf_counter() - t_red))   # (includes waiting for the slowest rank's segment)
             elif world > 1:
                 # (BENCH_SHARE_DEVICE: all ranks on one device, exchange over gloo -- a flow check, RCCL refuses it)
                 dist.all_reduce(frames, op=dist.ReduceOp.SUM)
@@ -320,12 +339,48 @@ def main():
             after = float(part.sum().item())
             want = float(before.item())
             exact = lay.wsed_offset >= 0
-            if rank == 0 and (after != want if exact else abs(after - want) > 1e-9 * abs(want)):
+            failed = torch.tensor([1.0 if (rank == 0 and (after != want if exact else abs(after - want) > 1e-9 * abs(want))) else 0.0],
+                                  dtype=torch.float64, device=f"cuda:{local_rank}")
+            if world > 1:
+                dist.all_reduce(failed, op=dist.ReduceOp.MAX)   # (every rank leaves together: none is left waiting in a collective)
+            if float(failed.item()) != 0.0:
                 raise SystemExit(f"reduce check failed: rank 0 holds {after!r} after the reduce, the ranks held {want!r} before it")
             reduce_check = {"quantity": "sum of wsed[0] of the first instrument (integer counts)" if exact else "sum of the frames",
                             "histories": n_check, "rank0_after_reduce": after, "sum_over_ranks_before": want}
         grid = scene_head(sim).grid
+        # behind the timed region: the kernels of this build one after the other -- ONE slot group, peel-off and propagation kernel in
+        # series, HIP events per kernel kind -- on a fifth of a step, so that the line can name its dominant kernel with that kernel's
+        # own time (the overlapped segment cannot: its kernels share the device)
+        breakdown = None
+        if rank == 0 and grid.kind == 2 and not args.no_breakdown:
+            eng.close()
+            keep = {k: os.environ.get(k) for k in ("PMC_NUM_GROUPS", "PMC_SERIAL_WALKS")}
+            os.environ["PMC_NUM_GROUPS"], os.environ["PMC_SERIAL_WALKS"] = "1", "1"
+            try:
+                one = Engine(sim.scene, local_rank)
+                one.bind_frames(frames.data_ptr(), frames.numel())
+                nb = max(1000000, history_range(total_per_step, rank, world)[1] // 5)
+                one.run_primary((warmup + steps + 2) * total_per_step, nb // 10, seed)
+                one.sync()
+                one.reset_counters()
+                one.run_primary((warmup + steps + 3) * total_per_step, nb, seed)
+                one.sync()
+                t, k, w, c = one.last_timing(), one.last_walk_timing(), one.walk_work(), one.counters()
+                breakdown = {"packets": nb, "segment_ms": t["total_ms"], "peel_ms": k["peel_ms"], "prop_ms": k["prop_ms"],
+                             "transition_side_ms": t["transition_ms"], "peel_lane_steps": w["peel_lane_steps"], "prop_lane_steps": w["prop_lane_steps"],
+                             "peel_lanes_in_use": w["peel_lane_steps"] / (64.0 * max(1, w["peel_wave_steps"])),
+                             "prop_lanes_in_use": w["prop_lane_steps"] / (64.0 * max(1, w["prop_wave_steps"])),
+                             "rewalk_visits": c["rewalk_visits"], "cell_visits": c["cell_visits"]}
+                one.close()
+            finally:
+                for k, v in keep.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            frames.zero_()
         result = {"elapsed": elapsed, "timings": timings, "counters": counters, "cells": int(grid.num_cells), "steps": steps,
+                  "breakdown": breakdown, "setup_s": setup_s, "reduce_ms": (sum(reduce_ms[warmup:]) / max(1, len(reduce_ms[warmup:]))) if reduce_ms else None,
                   "reduce_check": reduce_check, "walk_work": walk_work,
                   "packets_this_rank": history_range(total_per_step, rank, world)[1],
                   "vnbr_mean": (grid.vnbr_start[grid.num_cells] / grid.num_cells) if args.config == 5 else None}
@@ -358,21 +413,39 @@ def main():
         extra = {}
         w = m["walk_work"]
         if w["prop_wave_steps"] and w["peel_wave_steps"]:
-            # octree: secondary yardsticks.  A lane-step is one cell visit by one lane (first pass, second pass and peel-off
-            # walks alike): one dependent 32-byte gather.  gather_frac prices the whole step against the measured rate of
-            # dependent random 32-byte gathers through a 32 MB table on this chip (GATHER_CEILING, profiles/microbench/
-            # gather_knee_mi355x.txt); the per-kernel figures divide each kernel's own work by its own span (the spans of the
-            # two kernels overlap on two streams, and with the other slot groups' kernels).
+            # octree: secondary yardsticks.  A lane-step is one cell visit by one lane (first pass, second pass and peel-off walks
+            # alike): one dependent gather of a line of the hot cell table.  The chip's rate of such gathers depends on their locality
+            # alone (profiles/r04_bridge.md): GATHER_NO_LOCALITY for a table of this size without any, GATHER_L2_RESIDENT when every
+            # request hits L2.  The per-kernel figures divide each kernel's own work by its own span (the spans of the two kernels
+            # overlap on two streams, and with the other slot groups' kernels).
             peel_ms = sum(t["peel_ms"] for t in m["timings"]) / len(m["timings"])
             prop_ms = sum(t["prop_ms"] for t in m["timings"]) / len(m["timings"])
             peel_ls, prop_ls = w["peel_lane_steps"] / launches, w["prop_lane_steps"] / launches
-            extra = {"gather_frac": (peel_ls + prop_ls) / (mean_ms_of(m) * 1e-3) / GATHER_CEILING,
-                     "gather_ceiling": GATHER_CEILING, "gather_ceiling_source": "profiles/microbench/gather_knee_mi355x.txt",
+            extra = {"lane_steps_per_s": (peel_ls + prop_ls) / (mean_ms_of(m) * 1e-3),
+                     "gather_rate_no_locality": GATHER_NO_LOCALITY, "gather_rate_l2_resident": GATHER_L2_RESIDENT,
+                     "gather_rates_source": "profiles/microbench/true_gather_mi355x.txt (private trajectories; profiles/r04_bridge.md)",
                      "lane_steps_per_packet": (peel_ls + prop_ls) / n,
                      "prop": {"span_ms": prop_ms, "lane_steps_per_s": prop_ls / (prop_ms * 1e-3), "frac": 20.0 * prop_ls / (prop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "lanes_in_use": w["prop_lane_steps"] / (64.0 * w["prop_wave_steps"])},
                      "peel": {"span_ms": peel_ms, "lane_steps_per_s": peel_ls / (peel_ms * 1e-3), "frac": 20.0 * peel_ls / (peel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "lanes_in_use": w["peel_lane_steps"] / (64.0 * w["peel_wave_steps"])}}
+        b = m.get("breakdown")
+        if b:
+            # the dominant kernel by its OWN time: the kernels of one slot group in series (measured behind the timed region on
+            # b["packets"] packets), scaled to one step of this rank; algorithmic bytes = 20 B x the cell visits of the reference's
+            # paths that kernel walks (the propagation kernel's second-pass re-walk is work of this engine, not of the algorithm)
+            scale = n / b["packets"]
+            prop_visits = b["prop_lane_steps"] - b["rewalk_visits"]
+            kernels = {"walkPropKernel": (b["prop_ms"], 20.0 * prop_visits), "walkPeelKernel2": (b["peel_ms"], 20.0 * b["peel_lane_steps"])}
+            name = max(kernels, key=lambda k: kernels[k][0])
+            ms, nbytes = kernels[name]
+            extra["dominant_kernel"] = {"name": name, "serial_ms_per_step": ms * scale, "algorithmic_bytes_per_step": nbytes * scale,
+                                        "achieved": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "lane_steps_per_s": (b["prop_lane_steps"] if name == "walkPropKernel" else b["peel_lane_steps"]) / (ms * 1e-3),
+                                        "measured": f"one slot group, kernels in series, {b['packets']} packets behind the timed region of this run"}
+            extra["serial_kernel_ms_per_step"] = {"walkPropKernel": b["prop_ms"] * scale, "walkPeelKernel2": b["peel_ms"] * scale,
+                                                  "launch + transition + cycle start + scan": b["transition_side_ms"] * scale,
+                                                  "segment": b["segment_ms"] * scale}
         return {**extra, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "kernel_ms": mean_ms, "segment_ms": mean_ms,
                 "walk_kernel_ms_sum": sum(t["walk_ms"] for t in m["timings"]) / len(m["timings"]),
@@ -385,7 +458,8 @@ def main():
     main_run = measure(ski_path, args.steps, args.warmup)
     # the second source north_star names, measured in the same run on the same octree (default workload only): three steps
     secondary = None
-    if args.config == 2 and args.source == "sersic" and not args.store_radiation_field and args.ski == SKI and not args.no_secondary:
+    if args.config == 2 and args.source == "sersic" and not args.store_radiation_field and args.ski == SKI and not args.no_secondary \
+            and (world == 1 or args.secondary):
         text = open(SKI).read()
         new = ('<UniformBoxGeometry minX="-10000 pc" maxX="10000 pc" minY="-10000 pc" maxY="10000 pc" '
                'minZ="-1000 pc" maxZ="1000 pc"/>')
@@ -397,10 +471,12 @@ def main():
 
     if rank == 0:
         roof = roofline_of(main_run)
-        traffic, traffic_source = pmc_traffic(main_run["packets_this_rank"]) if (args.ski == SKI and args.source == "sersic" and args.config == 2) else (None, None)
+        traffic, traffic_all, traffic_source = pmc_traffic(main_run["packets_this_rank"]) if (args.ski == SKI and args.source == "sersic" and args.config == 2) else (None, None, None)
         roof["traffic"] = traffic
-        roof["traffic_source"] = (traffic_source + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this build on a step of 2e7 packets, "
-                                  "scaled by the packet count (not collected in this run)") if traffic_source else None
+        roof["traffic_all_kernels"] = traffic_all
+        roof["traffic_measured_in_run"] = False
+        roof["traffic_source"] = (traffic_source + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/run_profile_set.sh) over a step of 2e7 packets, "
+                                  "scaled by the packet count; `traffic` = the walk kernels, `traffic_all_kernels` = every kernel of the step") if traffic_source else None
         roof["kernel"] = ("walkKernel<Voronoi>" if args.config == 5 else "walkPeelKernel + walkPropKernel (octree)") + \
                          ": all launches of one step, overlapped on the slot groups' streams (denominator: segment_ms)"
         value = total_per_step * args.steps / main_run["elapsed"]
@@ -454,10 +530,24 @@ def main():
                                 "roofline": {k: sroof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "segment_ms",
                                                                    "cell_visits_per_packet", "detector_updates_per_packet",
                                                                    "algorithmic_bytes_per_packet")}}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
+            # (N > 1: on rank 0's host cores behind the timed region, while the other ranks wait at the final barrier)
             out["cpu_baseline"] = cpu_baseline(args.ski if args.source == "sersic" else ski_path, os.environ.get("SKH_INPUT_PATH"))
         else:
             out["cpu_baseline"] = None
+    else:
+        out = None
+    if world > 1:
+        # what every rank measured by itself: its packets, the mean GPU time of its segments, the time its reduce call took (it includes
+        # waiting for the slowest rank), and the time until its engine existed (rank 0: the scene set-up; the others: waiting for it and
+        # loading the scene file)
+        mine = {"rank": rank, "packets_per_step": main_run["packets_this_rank"], "segment_ms": mean_ms_of(main_run), "reduce_ms": main_run["reduce_ms"],
+                "setup_s": main_run["setup_s"]}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        if rank == 0:
+            out["per_rank"] = every
+    if rank == 0:
         line = json.dumps(out)
     else:
         line = None

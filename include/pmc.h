@@ -330,14 +330,14 @@ typedef struct pmc_walk_work_values
     uint64_t prop_wave_steps, prop_lane_steps, prop_rounds;
 } pmc_walk_work_values;
 int pmc_walk_work(pmc_ctx* ctx, pmc_walk_work_values* out);
-/* Tuning aid: DEVICE addresses of the octree walk's hot table (one 32-byte record per cell: f64 number density + six 4-byte
-   links, see skirt9_amd/csrc/pmc_device.h CellRec) and of the first cells of the propagation walks the last generations left in
+/* Tuning aid: DEVICE addresses of the octree walk's hot table (see skirt9_amd/csrc/pmc_device.h) and of the first cells of the propagation walks the last generations left in
    the task records -- so that profiles/microbench/bridge.hip can replay the walk's memory accesses on the scene's own tables.
    No reference counterpart; nothing in the product reads it. */
 typedef struct pmc_debug_table_values
 {
-    const void* cell_table;   /* [cell_slots] 32-byte records */
+    const void* cell_table;   /* [cell_slots] 32-byte records (pmc_device.h CellRec) */
     int64_t cell_slots;
+    int64_t loose_base;       /* = cell_slots (the octet-line table of profiles/experiments/r04_octet_line_table.patch: first loose leaf) */
     const int32_t* task_cell; /* [num_slots] first cell of the propagation walk of every slot (stale after the segment's end) */
     int64_t num_slots;
 } pmc_debug_table_values;

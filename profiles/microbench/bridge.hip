@@ -22,7 +22,7 @@
 namespace
 {
     constexpr uint32_t LINK_NONE = 0x7FFFFFFFu, LINK_NODE = 0x80000000u, LINK_OCTET = 0x40000000u, LINK_INDEX = 0x3FFFFFFu;
-    enum : int { F_REAL = 1, F_BODY = 2, F_LDS = 4, F_ROUNDS = 8, F_IO = 16, F_TRIM = 32 };
+    enum : int { F_REAL = 1, F_BODY = 2, F_LDS = 4, F_ROUNDS = 8, F_IO = 16, F_TRIM = 32, F_OCT = 64 };
 
     struct Args
     {
@@ -38,6 +38,7 @@ namespace
         int refill;
         int meanLength;           // random chase: mean walk length (REAL: cap on the length)
         uint32_t tabEntries;      // coordinate table entries per axis (1025)
+        uint32_t looseBase;       // F_OCT: first loose cell of the octet-line table (generation-8 experiment)
     };
 
     __device__ __forceinline__ uint32_t mix(uint32_t x)
@@ -57,7 +58,7 @@ namespace
     typedef __attribute__((address_space(3))) const double LdsDouble;
     __device__ __forceinline__ double ldsAt(uint32_t byteOffset) { return *reinterpret_cast<LdsDouble*>(static_cast<uintptr_t>(byteOffset)); }
 
-    template<int F> __global__ __launch_bounds__(768, 3) void walk(const Args A)
+    template<int F> __global__ __launch_bounds__(1024) void walk(const Args A)
     {
         extern __shared__ double lds[];
         const int tid = threadIdx.x, lane = tid & 63, block = blockDim.x;
@@ -81,10 +82,28 @@ namespace
         uint32_t sinkU = 0;
         const unsigned long long below = (1ull << lane) - 1ull;
 
+        auto sibl = [&](uint32_t cell, uint32_t ax) { return cell < A.looseBase && ((cell >> ax) & 1u) != (((sgn >> ax) & 1u) ^ 1u); };
         auto issue = [&](uint32_t cell) {
-            const uint4* p = A.table + 2ull * cell;
-            ga = p[0];
-            gb = p[1];
+            if (F & F_OCT)
+            {
+                // octet-line table: 8 bytes of density now; the link (4 bytes of the same line) when the exit axis is known
+                const char* line = reinterpret_cast<const char*>(A.table) + ((size_t)(cell >> 3) << 7);
+                const uint2 v = *reinterpret_cast<const uint2*>(line + ((cell & 7u) << 3));
+                ga.x = v.x, ga.y = v.y;
+            }
+            else
+            {
+                const uint4* p = A.table + 2ull * cell;
+                ga = p[0];
+                gb = p[1];
+            }
+        };
+        auto issueLink = [&](uint32_t cell, uint32_t ax) {
+            if ((F & F_OCT) && !sibl(cell, ax))
+            {
+                const char* line = reinterpret_cast<const char*>(A.table) + ((size_t)(cell >> 3) << 7);
+                ga.z = *reinterpret_cast<const uint32_t*>(line + 64u + ((2u * ax + (((sgn >> ax) & 1u) ^ 1u)) << 2));
+            }
         };
         // a new walk for this lane (no memory apart from the start list)
         auto restart = [&]() {
@@ -152,7 +171,11 @@ namespace
                     restart();
                     ikx = 1. / kx, iky = 1. / ky, ikz = 1. / kz;
                 }
-                if (want && active) issue(idx);
+                if (want && active)
+                {
+                    issue(idx);
+                    issueLink(idx, axis);
+                }
             }
             // ---------------- steps
 #pragma unroll 1
@@ -166,7 +189,17 @@ namespace
                     const double nrx = rx + kx * step, nry = ry + ky * step, nrz = rz + kz * step;
                     // the record of the current cell: density and the link through the exit wall
                     const uint32_t fx = (sgn & 1u) ? ga.z : ga.w, fy = (sgn & 2u) ? gb.x : gb.y, fz = (sgn & 4u) ? gb.z : gb.w;
-                    const uint32_t link = axis == 0u ? fx : axis == 1u ? fy : fz;
+                    uint32_t link = axis == 0u ? fx : axis == 1u ? fy : fz;
+                    if (F & F_OCT)
+                    {
+                        // a sibling needs no link; a same-size octet across the wall: the mirror child
+                        const bool sib = sibl(idx, axis);
+                        link = ga.z;
+                        if (sib)
+                            link = (idx ^ (1u << axis)) << 4;
+                        else if (idx < A.looseBase && (link & 0xC0000000u) == LINK_OCTET && link != LINK_NONE)
+                            link = (((link >> 4) & LINK_INDEX) | ((idx & 7u) ^ (1u << axis))) << 4;
+                    }
                     const double dens = __longlong_as_double(((long long)ga.y << 32) | ga.x);
                     const double tau1 = tau + sext * dens * ds;
                     if ((F & F_TRIM) && nrec < 5u)
@@ -199,6 +232,11 @@ namespace
                     {
                         issue(next);
                         idx = next;
+                        if ((F & F_OCT) && !(F & F_BODY))
+                        {
+                            axis = (mix(next + nrec) >> 5) % 3u;
+                            issueLink(next, axis);
+                        }
                         if (F & F_BODY)
                         {
                             // treeEnterBox: box of the next cell (here: table offsets from a hash of its index), strict inside test,
@@ -229,8 +267,9 @@ namespace
                             axis = (dsx == m) ? 0u : (dsy == m) ? 1u : 2u;
                             ds = fabs(m) * 1e-3 + 1e-4;
                             rx = fxr, ry = fyr, rz = fzr;
+                            issueLink(next, axis);
                         }
-                        else
+                        else if (!(F & F_OCT))
                         {
                             axis = (mix(next + nrec) >> 5) % 3u;
                             sinkD += nrx + nry + nrz;
@@ -270,7 +309,7 @@ namespace
 
 // runs one variant; out[0] = ms, out[1] = lane-steps, out[2] = wave-steps, out[3] = rounds, out[4] = walks
 extern "C" int bridge_run(int flags, const void* table, uint32_t records, const int32_t* starts, uint32_t numStarts, int grid, int block, int steps,
-                          int refill, int meanLength, double* out)
+                          int refill, int meanLength, double* out, uint32_t looseBase)
 {
     static double* slotIn = nullptr;
     static double* slotOut = nullptr;
@@ -283,7 +322,7 @@ extern "C" int bridge_run(int flags, const void* table, uint32_t records, const 
         hipMalloc(&counters, 8 * sizeof(unsigned long long));
         hipMemset(slotIn, 0x3f, size_t(12) * slotCap * sizeof(double));  // (doubles around 4.7e-4)
     }
-    Args a = {reinterpret_cast<const uint4*>(table), records, starts, numStarts, slotIn, slotOut, slotCap, counters, steps, refill, meanLength, 1025u};
+    Args a = {reinterpret_cast<const uint4*>(table), records, starts, numStarts, slotIn, slotOut, slotCap, counters, steps, refill, meanLength, 1025u, looseBase};
     const size_t ldsBytes = size_t(3) * 1025 * 8 + ((flags & F_TRIM) ? size_t(block) * 172 : 0);
     float ms = 0;
     int rc = 1;
@@ -291,7 +330,7 @@ extern "C" int bridge_run(int flags, const void* table, uint32_t records, const 
     {
 #define CASE(f) case f: rc = launch<f>(a, grid, block, ldsBytes, &ms); break;
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(6) CASE(7) CASE(8) CASE(9) CASE(14) CASE(15) CASE(24) CASE(25) CASE(30) CASE(31) CASE(62) CASE(63)
-        CASE(10) CASE(11) CASE(27) CASE(59)
+        CASE(10) CASE(11) CASE(27) CASE(59) CASE(65) CASE(71) CASE(73) CASE(127) CASE(95)
 #undef CASE
         default: return 2;
     }
@@ -447,6 +486,101 @@ extern "C" double bridge_true_gather(int loads, int priv, const void* table, uin
         *distinct = double(std::unique(host, host + n) - host);
         delete[] host;
     }
+    return double(grid) * block * steps / (ms * 1e-3);
+}
+
+// The CU's own limit: private trajectories (no merging) on FEW CUs, so that L2 and fabric are far from their limits; what one
+// lane-step asks of the vector memory pipeline is varied.  SHAPE 0: one 16-byte load; 1: two 16-byte loads of one 32-byte record;
+// 2: an 8-byte and a 4-byte load of one 128-byte line (8 B at 8 j, 4 B at 64 + 4 w); 3: 8 + 16 + 8 bytes of one line; 4: two 16-byte
+// loads of two different lines; 5: one 8-byte load; 6: as 1 with a scalar base and 32-bit vector offsets
+namespace
+{
+    template<int SHAPE> __global__ __launch_bounds__(1024) void chaseShape(const char* __restrict__ table, unsigned mask, int steps, unsigned* final, const unsigned long long zero)
+    {
+        const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+        unsigned idx = (tid * 2654435761u) & mask;  // index of a 128-byte line
+        const unsigned salt = tid * 0x85ebca6bu + 0x27d4eb2fu;
+        unsigned acc = 0;
+        const char* base = table + (zero & tid);  // (a per-lane 64-bit address, as in the walk kernels)
+#pragma unroll 1
+        for (int i = 0; i < steps; ++i)
+        {
+            unsigned link;
+            const unsigned sub = (idx ^ i) & 7u;
+            if (SHAPE == 0)
+            {
+                const uint4 a = *reinterpret_cast<const uint4*>(base + ((size_t)idx << 7) + ((sub & 3u) << 5));
+                link = a.x ^ a.w, acc += a.y;
+            }
+            else if (SHAPE == 1)
+            {
+                const char* p = base + ((size_t)idx << 7) + ((sub & 3u) << 5);
+                const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 16);
+                link = a.x ^ b.z, acc += a.y + b.w;
+            }
+            else if (SHAPE == 2)
+            {
+                const char* p = base + ((size_t)idx << 7);
+                const uint2 a = *reinterpret_cast<const uint2*>(p + (sub << 3));
+                const unsigned b = *reinterpret_cast<const unsigned*>(p + 64 + ((sub % 6u) << 2));
+                link = a.x ^ b, acc += a.y;
+            }
+            else if (SHAPE == 3)
+            {
+                const char* p = base + ((size_t)idx << 7);
+                const uint2 a = *reinterpret_cast<const uint2*>(p + (sub << 3));
+                const uint4 b = *reinterpret_cast<const uint4*>(p + 64);
+                const uint2 c = *reinterpret_cast<const uint2*>(p + 80);
+                link = a.x ^ b.z ^ c.y, acc += a.y + b.x + c.x;
+            }
+            else if (SHAPE == 4)
+            {
+                const uint4 a = *reinterpret_cast<const uint4*>(base + ((size_t)idx << 7));
+                const uint4 b = *reinterpret_cast<const uint4*>(base + ((size_t)((idx * 2654435761u + 12345u) & mask) << 7));
+                link = a.x ^ b.z, acc += a.y + b.w;
+            }
+            else if (SHAPE == 5)
+            {
+                const uint2 a = *reinterpret_cast<const uint2*>(base + ((size_t)idx << 7) + (sub << 3));
+                link = a.x, acc += a.y;
+            }
+            else
+            {
+                const unsigned off = (idx << 7) + ((sub & 3u) << 5);
+                const uint4 a = *reinterpret_cast<const uint4*>(table + off), b = *reinterpret_cast<const uint4*>(table + off + 16);
+                link = a.x ^ b.z, acc += a.y + b.w;
+            }
+            idx = ((link ^ salt) + i * 0x9E3779B1u) & mask;
+        }
+        final[tid] = idx + (acc & 0u);
+    }
+}
+extern "C" double bridge_shape(int shape, const void* table, uint32_t lines, int grid, int block, int steps)
+{
+    static unsigned* out = nullptr;
+    if (!out) hipMalloc(&out, size_t(2048) * 1024 * sizeof(unsigned));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    const char* t = reinterpret_cast<const char*>(table);
+    auto go = [&](int n) {
+        switch (shape)
+        {
+            case 0: hipLaunchKernelGGL(chaseShape<0>, dim3(grid), dim3(block), 0, 0, t, lines - 1u, n, out, 0ull); break;
+            case 1: hipLaunchKernelGGL(chaseShape<1>, dim3(grid), dim3(block), 0, 0, t, lines - 1u, n, out, 0ull); break;
+            case 2: hipLaunchKernelGGL(chaseShape<2>, dim3(grid), dim3(block), 0, 0, t, lines - 1u, n, out, 0ull); break;
+            case 3: hipLaunchKernelGGL(chaseShape<3>, dim3(grid), dim3(block), 0, 0, t, lines - 1u, n, out, 0ull); break;
+            case 4: hipLaunchKernelGGL(chaseShape<4>, dim3(grid), dim3(block), 0, 0, t, lines - 1u, n, out, 0ull); break;
+            case 5: hipLaunchKernelGGL(chaseShape<5>, dim3(grid), dim3(block), 0, 0, t, lines - 1u, n, out, 0ull); break;
+            default: hipLaunchKernelGGL(chaseShape<6>, dim3(grid), dim3(block), 0, 0, t, lines - 1u, n, out, 0ull); break;
+        }
+    };
+    go(10);
+    hipEventRecord(e0);
+    go(steps);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
     return double(grid) * block * steps / (ms * 1e-3);
 }
 

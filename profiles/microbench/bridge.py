@@ -13,7 +13,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-F = {"REAL": 1, "BODY": 2, "LDS": 4, "ROUNDS": 8, "IO": 16, "TRIM": 32}
+F = {"REAL": 1, "BODY": 2, "LDS": 4, "ROUNDS": 8, "IO": 16, "TRIM": 32, "OCT": 64}
 
 
 def main():
@@ -37,23 +37,23 @@ def main():
     eng.sync()
     t = eng.debug_tables()
     B = C.CDLL(os.path.join(ROOT, "profiles", "microbench", "libbridge.so"))
-    B.bridge_run.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    B.bridge_run.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_uint32]
     B.bridge_random_table.restype = C.c_void_p
     B.bridge_random_table.argtypes = [C.c_uint32]
     rnd = B.bridge_random_table(1 << 20)  # 32 MB of 32-byte records
     out = (C.c_double * 8)()
 
-    def run(name, flags, block=768, refill=40, steps=args.steps, length=80):
+    def run(name, flags, block=768, refill=40, steps=args.steps, length=80, grid=256):
         f = sum(F[k] for k in flags)
         real = "REAL" in flags
-        rc = B.bridge_run(f, t.cell_table if real else rnd, int(t.cell_slots) if real else (1 << 20), t.task_cell, min(int(t.num_slots), n), 256, block, steps,
-                          refill, 4000 if real else length, out)
+        rc = B.bridge_run(f, t.cell_table if real else rnd, int(t.cell_slots) if real else (1 << 20), t.task_cell, min(int(t.num_slots), n), grid, block, steps,
+                          refill, 4000 if real else length, out, int(getattr(t, 'loose_base', 0)))
         if rc:
             print(f"{name:70s} FAILED rc={rc}", flush=True)
             return
         ms, lane, wave, rounds, walks = out[0], out[1], out[2], out[3], out[4]
-        print(f"{name:70s} {block // 64:2d} waves/CU  {lane / ms / 1e8:6.3f}e11 lane-steps/s  lanes {100 * lane / (64 * wave):5.1f} %  "
-              f"{ms * 1e6 / (wave / (256 * block // 64)):7.0f} ns/wave-step  steps/walk {lane / max(walks, 1):6.1f}  rounds/wave-step {rounds / wave:.4f}", flush=True)
+        print(f"{name:70s} {grid:4d} x {block // 64:2d} waves  {lane / ms / 1e8:6.3f}e11 lane-steps/s  lanes {100 * lane / (64 * wave):5.1f} %  "
+              f"{ms * 1e6 / (wave / (grid * block // 64)):7.0f} ns/wave-step  steps/walk {lane / max(walks, 1):6.1f}  rounds/wave-step {rounds / wave:.4f}", flush=True)
 
     print(f"# bridge: scene {os.path.basename(ski)}, {t.cell_slots} cells, source {args.source}")
     B.bridge_plain_chase.restype = C.c_double
@@ -69,6 +69,24 @@ def main():
     pow2 = 1 << (int(t.cell_slots).bit_length() - 1)
     print(f"plain chase over the first {pow2} records of the ENGINE's cell table (links as random numbers), 12 waves/CU: "
           f"{B.bridge_plain_chase(t.cell_table, pow2, 256, 768, 2000) / 1e11:.3f}e11 records/s")
+    if os.environ.get("BRIDGE_OCTET"):
+        # the octet-line table of the generation-8 experiment (engine built with it): the same walker on it
+        for block in (768, 512):
+            run("octet lines: real links, no body", ["REAL", "OCT"], block)
+            run("octet lines: real + body + LDS", ["REAL", "OCT", "BODY", "LDS"], block)
+            run("octet lines: real, rounds(40) free, no body", ["REAL", "OCT", "ROUNDS"], block)
+            run("octet lines: all ingredients", ["REAL", "OCT", "BODY", "LDS", "ROUNDS", "IO", "TRIM"], block)
+            run("octet lines: all but the recorded segments", ["REAL", "OCT", "BODY", "LDS", "ROUNDS", "IO"], block)
+        return
+    if os.environ.get("BRIDGE_SCALING"):
+        # does the rate belong to the CU or to the chip?  workgroups (one per CU) x waves per workgroup
+        for flags, name in ((["REAL"], "real table, real links, no body"), (["REAL", "BODY", "LDS", "ROUNDS", "IO", "TRIM"], "real, all ingredients"), ([], "random chase")):
+            for grid in (32, 64, 128, 256, 512):
+                for block in (128, 256, 512, 768, 1024):
+                    if grid == 512 and block > 512:
+                        continue
+                    run(name, flags, block, grid=grid)
+        return
     for block in (768, 512):
         run("random chase, 32 MB table (gather_knee)", [], block)
         run("+ real table, real links (walk locality)", ["REAL"], block)

@@ -1494,6 +1494,7 @@ int pmc_debug_tables(pmc_ctx* ctx, pmc_debug_table_values* out)
     if (ctx->dev.grid_kind != PMC_GRID_OCTREE) return fail(PMC_ERR_INVALID, "not an octree scene");
     out->cell_table = ctx->dev.cell_tab;
     out->cell_slots = ctx->dev.cell_slots;
+    out->loose_base = ctx->dev.cell_slots;
     out->task_cell = ctx->dev.tasks.cell;
     out->num_slots = ctx->allocatedSlots;
     return PMC_OK;

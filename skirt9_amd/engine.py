@@ -29,7 +29,7 @@ _lib = None
 
 class DebugTables(C.Structure):
     """pmc_debug_table_values (include/pmc.h): device addresses for profiles/microbench/bridge.hip"""
-    _fields_ = [("cell_table", C.c_void_p), ("cell_slots", C.c_int64), ("task_cell", C.c_void_p), ("num_slots", C.c_int64)]
+    _fields_ = [("cell_table", C.c_void_p), ("cell_slots", C.c_int64), ("loose_base", C.c_int64), ("task_cell", C.c_void_p), ("num_slots", C.c_int64)]
 
 
 class WalkWork(C.Structure):

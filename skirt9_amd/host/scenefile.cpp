@@ -18,8 +18,11 @@ extern const char* skh_set_error_text(const std::string& text);  // capi.cpp
 
 namespace
 {
-    constexpr uint64_t MAGIC = 0x31454e454353484bull;  // "KHSCENE1"
+    constexpr uint64_t MAGIC = 0x32454e454353484bull;  // "KHSCENE2"
 
+    // The loader trusts nothing in the file: the header names the sizes of the structures the writer was built with and a checksum
+    // of everything behind it; every member's [offset, offset + count * sizeof) is held against the file size before the offset
+    // becomes a pointer, and a count is only ever read through a member that passed that test.
     struct Header
     {
         uint64_t magic;
@@ -28,7 +31,28 @@ namespace
         int64_t frame_size, rf_size;
         int32_t num_instruments, pad;
         uint64_t scene_offset, layout_offset, total_bytes;
+        uint32_t sizeof_scene, sizeof_instrument, sizeof_source, sizeof_layout;
+        uint64_t checksum;  // FNV-1a (64 bit) of the bytes behind the header
     };
+
+    uint64_t fnv1a(const char* data, size_t bytes)
+    {
+        // eight interleaved lanes over 8-byte words (a scene file is tens to hundreds of MB), folded at the end
+        uint64_t h[8];
+        for (int k = 0; k < 8; ++k) h[k] = 0xcbf29ce484222325ull + uint64_t(k);
+        size_t i = 0;
+        for (; i + 64 <= bytes; i += 64)
+            for (int k = 0; k < 8; ++k)
+            {
+                uint64_t w;
+                std::memcpy(&w, data + i + 8 * k, 8);
+                h[k] = (h[k] ^ w) * 0x100000001b3ull;
+            }
+        uint64_t r = 0xcbf29ce484222325ull;
+        for (int k = 0; k < 8; ++k) r = (r ^ h[k]) * 0x100000001b3ull;
+        for (; i < bytes; ++i) r = (r ^ uint64_t((unsigned char)data[i])) * 0x100000001b3ull;
+        return r;
+    }
 
     // Every pointer member of a pmc_scene, in an order in which the element count of each is known from members visited before
     // it: f(pointer member, number of elements).  Used with the caller's arrays (save: append the data) and with offsets (load:
@@ -166,6 +190,9 @@ int skh_scene_save(const skh_simulation* h, const char* path)
         head.scene_offset = sceneAt;
         head.layout_offset = layoutAt;
         head.total_bytes = S.blob.size();
+        head.sizeof_scene = sizeof(pmc_scene), head.sizeof_instrument = sizeof(pmc_instrument), head.sizeof_source = sizeof(pmc_source);
+        head.sizeof_layout = sizeof(pmc_frame_layout);
+        head.checksum = fnv1a(S.blob.data() + sizeof(Header), S.blob.size() - sizeof(Header));
         std::memcpy(S.blob.data(), &head, sizeof(head));
         // (written under a temporary name and renamed: a reader never sees a partial file)
         const std::string tmp = std::string(path) + ".part";
@@ -201,15 +228,32 @@ skh_scene_file* skh_scene_load(const char* path)
         char* base = file->blob.data();
         const Header* head = reinterpret_cast<const Header*>(base);
         if (head->magic != MAGIC || head->total_bytes != uint64_t(size)) throw std::runtime_error(std::string(path) + " is not a scene file");
-        if (head->abi != PMC_ABI_VERSION) throw std::runtime_error(std::string(path) + " was written for another version of pmc_scene");
+        if (head->abi != PMC_ABI_VERSION || head->sizeof_scene != sizeof(pmc_scene) || head->sizeof_instrument != sizeof(pmc_instrument)
+            || head->sizeof_source != sizeof(pmc_source) || head->sizeof_layout != sizeof(pmc_frame_layout))
+            throw std::runtime_error(std::string(path) + " was written for another version of pmc_scene");
+        if (head->checksum != fnv1a(base + sizeof(Header), size_t(size) - sizeof(Header)))
+            throw std::runtime_error(std::string(path) + ": checksum mismatch (truncated or corrupt scene file)");
+        const uint64_t total = uint64_t(size);
+        auto inside = [&](uint64_t off, uint64_t count, uint64_t each) { return off >= sizeof(Header) && off % 8 == 0 && count <= total / each && off <= total - count * each; };
+        if (head->num_instruments < 0 || head->num_instruments > 4096 || !inside(head->scene_offset, 1, sizeof(pmc_scene))
+            || !inside(head->layout_offset, uint64_t(head->num_instruments), sizeof(pmc_frame_layout)))
+            throw std::runtime_error(std::string(path) + ": header offsets outside the file");
         pmc_scene& scene = *reinterpret_cast<pmc_scene*>(base + head->scene_offset);
-        // offsets back into pointers, in the visiting order (the count of a member is read through members rebased before it)
+        if (scene.num_instruments != head->num_instruments) throw std::runtime_error(std::string(path) + ": inconsistent instrument count");
+        // offsets back into pointers, in the visiting order (the count of a member is read through members rebased -- and bounds-checked
+        // -- before it; a negative count arrives here as a huge one and fails the test)
         visitScene(scene, [&](auto& member, size_t count) {
             typedef typename std::remove_reference<decltype(member)>::type P;
+            typedef typename std::remove_const<typename std::remove_pointer<P>::type>::type T;
             uint64_t off = 0;
             std::memcpy(&off, &member, sizeof(off));
-            if (off >= uint64_t(size)) throw std::runtime_error(std::string(path) + ": offset outside the file");
-            member = (off && count) ? reinterpret_cast<P>(base + off) : nullptr;
+            if (count == 0)
+            {
+                member = nullptr;
+                return;
+            }
+            if (!inside(off, count, sizeof(T))) throw std::runtime_error(std::string(path) + ": a table of the scene lies outside the file");
+            member = reinterpret_cast<P>(base + off);
         });
         file->header = head;
         file->scene = &scene;

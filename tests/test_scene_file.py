@@ -41,3 +41,56 @@ def test_a_file_that_is_not_a_scene_is_refused(tmp_path):
     bad.write_bytes(b"\0" * 4096)
     with pytest.raises(RuntimeError, match="not a scene file"):
         SceneFile(str(bad))
+
+
+def test_a_damaged_scene_file_is_refused(tmp_path):
+    """the loader trusts nothing in the file (skirt9_amd/host/scenefile.cpp): a truncated file, a flipped byte in the tables, and a
+    planted count or offset with a matching checksum are all refused before an offset becomes a pointer"""
+    import struct
+    sim = Simulation(ski("cfg2small.ski"), num_packets=100).setup()
+    path = tmp_path / "scene.bin"
+    sim.save_scene(str(path))
+    good = path.read_bytes()
+    SceneFile(str(path))
+    (tmp_path / "short.bin").write_bytes(good[:len(good) // 2])
+    with pytest.raises(RuntimeError, match="not a scene file"):
+        SceneFile(str(tmp_path / "short.bin"))
+    flipped = bytearray(good)
+    flipped[len(good) // 2] ^= 0x40
+    (tmp_path / "flipped.bin").write_bytes(bytes(flipped))
+    with pytest.raises(RuntimeError, match="checksum"):
+        SceneFile(str(tmp_path / "flipped.bin"))
+    # a writer that knows the checksum: offsets and counts are still held against the file size
+    header = struct.Struct("<QiiQQqqiiQQQIIIIQ")
+    fields = list(header.unpack_from(good))
+    assert fields[11] == len(good)
+
+    def resealed(data):
+        body = bytes(data[header.size:])
+        h = [(0xcbf29ce484222325 + k) & 0xFFFFFFFFFFFFFFFF for k in range(8)]
+        words = np.frombuffer(body[:len(body) // 64 * 64], dtype="<u8").reshape(-1, 8)
+        for row in words.tolist():
+            for k in range(8):
+                h[k] = ((h[k] ^ row[k]) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        r = 0xcbf29ce484222325
+        for k in range(8):
+            r = ((r ^ h[k]) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        for b in body[len(body) // 64 * 64:]:
+            r = ((r ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        f = list(header.unpack_from(data))
+        f[16] = r
+        header.pack_into(data, 0, *f)
+        return bytes(data)
+
+    assert resealed(bytearray(good)) == good          # (the test's checksum is the library's)
+    planted = bytearray(good)
+    scene_at = fields[9]
+    # the pointer members of the pmc_scene in the file are offsets: the first plausible one is sent to the last 8 bytes of the file
+    words = np.frombuffer(bytes(planted[scene_at:scene_at + 512]), dtype="<u8")
+    inside = [i for i, w in enumerate(words.tolist()) if header.size <= w < len(good) and w % 16 == 0]
+    assert inside, "no offset word found in the scene structure"
+    struct.pack_into("<Q", planted, scene_at + 8 * inside[0], len(good) - 8)
+    (tmp_path / "planted.bin").write_bytes(resealed(planted))
+    with pytest.raises(RuntimeError, match="outside the file"):
+        SceneFile(str(tmp_path / "planted.bin"))
+    sim.close()
