@@ -42,6 +42,9 @@ int64_t  skh_frame_size(const skh_simulation* sim);
 int skh_frame_layout(const skh_simulation* sim, int32_t instrument, pmc_frame_layout* out);
 /* calibrates `frames` in place and writes <prefix>_<instrument>_*.fits / _sed.dat / _sedstats.dat into outdir */
 int skh_write(const skh_simulation* sim, double* frames, const char* outdir);
+/* the same without the statistics files (_stats0..4.fits, _sedstats.dat): for a segment whose statistics arrays are incomplete
+   (pmc_run_primary returned PMC_ERR_OVERFLOW: the flux arrays are complete, the sums of w^k are not) */
+int skh_write_fluxes_only(const skh_simulation* sim, double* frames, const char* outdir);
 /* radiation field (RadiationFieldOptions::storeRadiationField): doubles of the table rf[m * nbins + ell] that
    pmc_download_radiation_field fills (0: not stored), and the RadiationFieldProbe / PerCellForm files
    <prefix>_<probe>_J.dat written from it (RadiationFieldProbe.cpp:27-78, PerCellForm.cpp:14-32) */

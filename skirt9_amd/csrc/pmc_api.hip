@@ -498,6 +498,17 @@ namespace
             const int minEvents = D.min_scatt_events;
             int64_t blocks = minEvents > 16 ? n * int64_t((minEvents + 2 * PMC_STAT_CAP - 1) / PMC_STAT_CAP) : n / 4;
             blocks = std::max<int64_t>(blocks, 1024) * D.num_instruments;
+            // (... and up to one block per slot and instrument where an eighth of the free device memory allows it: the sparse
+            // generations at the end of a segment keep the blocks of retired histories out of the pool, and a long non-forced history
+            // in an optically thick medium needs more than the default)
+            {
+                size_t freeBytes = 0, totalBytes = 0;
+                if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess)
+                {
+                    const int64_t afford = int64_t(freeBytes / 8 / (PMC_STAT_CAP * 12 + 12));
+                    blocks = std::max(blocks, std::min<int64_t>(n * int64_t(D.num_instruments), afford));
+                }
+            }
             if (const char* env = getenv("PMC_STAT_POOL_BLOCKS")) blocks = std::max<int64_t>(PMC_MAX_GROUPS, atoll(env));
             blocks = std::min<int64_t>(blocks, int64_t(1) << 30);
             if ((rc = ctx->allocate<int32_t>(size_t(blocks) * PMC_STAT_CAP, &D.stat_pool_bin, false, &own))) return rc;

@@ -186,6 +186,19 @@ int64_t skh_radiation_field_size(const skh_simulation* h)
 }
 
 // writes the RadiationFieldProbe files from the table rf[m * nbins + ell]
+int skh_write_fluxes_only(const skh_simulation* h, double* frames, const char* outdir)
+{
+    try
+    {
+        h->sim->write(frames, outdir, false);
+        return 0;
+    }
+    catch (const std::exception& e)
+    {
+        return fail(e);
+    }
+}
+
 int skh_write_radiation_field(const skh_simulation* h, const double* rf, const char* outdir)
 {
     try

@@ -117,7 +117,7 @@ int main(int argc, char** argv)
            useComm ? " (detector arrays summed over RCCL)" : "");
     auto t2 = clock::now();
     std::vector<pmc_ctx*> ctxs(G, nullptr);
-    std::vector<std::string> errors(G);
+    std::vector<std::string> errors(G), statisticsLost(G);
     std::vector<pmc_counter_values> counts(G);
     std::vector<double> frames(skh_frame_size(sim));
     std::vector<double> rf(skh_radiation_field_size(sim));
@@ -144,7 +144,11 @@ int main(int argc, char** argv)
         {
             uint64_t first = 0, count = 0;
             pmc_history_range(n, g, G, &first, &count);
-            ok = pmc_run_primary(ctxs[g], first, count, (uint64_t)skh_seed(sim)) == PMC_OK;
+            const int rc = pmc_run_primary(ctxs[g], first, count, (uint64_t)skh_seed(sim));
+            // (the pool of statistics list blocks ran out: the flux arrays of the segment are complete, its sums of w^k are not --
+            // the run goes on, and the statistics files are left out below)
+            if (rc == PMC_ERR_OVERFLOW) statisticsLost[g] = pmc_last_error();
+            ok = rc == PMC_OK || rc == PMC_ERR_OVERFLOW;
         }
         if (!ok) failed();
         if (ok) pmc_counters(ctxs[g], &counts[g]);
@@ -179,15 +183,17 @@ int main(int argc, char** argv)
     }
     printf("Finished primary emission in %.3f s (%.3g packets/s; %.1f cell visits and %.1f detector updates per packet).\n",
            seconds(t2, t3), n / seconds(t2, t3), (double)c.cell_visits / n, (double)c.detector_updates / n);
-    if (c.stat_overflows)
-    {
-        // FluxRecorder::recordContributions keeps every contribution of a history (FluxRecorder.cpp:962-1014); the engine's
-        // per-history list is bounded, and statistics computed from a truncated list would be wrong: no output
-        fprintf(stderr, "Fatal error: %llu photon histories contributed to more distinct pixels of an instrument than the engine's "
-                        "statistics list holds; rerun with recordStatistics=\"false\"\n", (unsigned long long)c.stat_overflows);
-        return 1;
-    }
-    if (skh_write(sim, frames.data(), outdir.c_str()) != 0)
+    bool lost = false;
+    for (int g = 0; g < G; ++g)
+        if (!statisticsLost[g].empty())
+        {
+            // FluxRecorder::recordContributions keeps every contribution of a history (FluxRecorder.cpp:962-1014); the engine keeps them
+            // in blocks from a pool, and statistics computed from truncated lists would be wrong: the statistics files are not written
+            fprintf(stderr, "Warning (device %d): %s\n", devices[g], statisticsLost[g].c_str());
+            lost = true;
+        }
+    if (lost) fprintf(stderr, "Warning: the statistics files (_stats*.fits, _sedstats.dat) are NOT written; the flux files are complete.\n");
+    if ((lost ? skh_write_fluxes_only(sim, frames.data(), outdir.c_str()) : skh_write(sim, frames.data(), outdir.c_str())) != 0)
     {
         fprintf(stderr, "Fatal error: %s\n", skh_last_error());
         return 1;

@@ -304,7 +304,7 @@ namespace skh
         return files;
     }
 
-    std::vector<std::string> Simulation::write(double* frames, const std::string& outdir) const
+    std::vector<std::string> Simulation::write(double* frames, const std::string& outdir, bool writeStatistics) const
     {
         std::vector<std::string> files;
         std::string base = outdir;
@@ -398,7 +398,7 @@ namespace skh
                     }
                 }
                 files.push_back(path);
-                if (L.wsed_offset >= 0)
+                if (L.wsed_offset >= 0 && writeStatistics)
                 {
                     const double* wsed = frames + L.wsed_offset;
                     std::string spath = base + ins.name + "_sedstats.dat";
@@ -471,7 +471,7 @@ namespace skh
                     files.push_back(path);
                 }
 
-                if (L.wifu_offset >= 0)
+                if (L.wifu_offset >= 0 && writeStatistics)
                 {
                     double* wifu = frames + L.wifu_offset;  // [k][lell]
                     const double WMAX = 1e38;

@@ -39,7 +39,8 @@ namespace skh
 
         // FluxRecorder::calibrateAndWrite for every instrument (FluxRecorder.cpp:484-846); frames holds the raw
         // detector arrays in the pmc_frame_layout order and is calibrated IN PLACE.  Returns the files written.
-        std::vector<std::string> write(double* frames, const std::string& outdir) const;
+        // writeStatistics = false: the flux files only (a segment whose statistics arrays are incomplete: the engine's list pool ran out)
+        std::vector<std::string> write(double* frames, const std::string& outdir, bool writeStatistics = true) const;
 
         // Radiation field (RadiationFieldOptions::storeRadiationField): number of doubles of the table rf[m * nbins + ell]
         // that pmc_download_radiation_field fills (0 if not stored), and the RadiationFieldProbe / PerCellForm output
