@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 6
+#define PMC_ABI_VERSION 7
 
 enum { PMC_OK = 0, PMC_ERR_INVALID = -1, PMC_ERR_UNSUPPORTED = -2, PMC_ERR_DEVICE = -3, PMC_ERR_NOMEM = -4,
        PMC_ERR_OVERFLOW = -5 /* the pool of statistics-list blocks ran out during the segment (see pmc_run_primary) */ };
@@ -110,6 +110,8 @@ typedef struct pmc_medium
     const double* sigma_ext;        /* num_lambda */
     const double* sigma_sca;        /* num_lambda */
     const double* asymmpar;         /* num_lambda, already clamped to +-0.999999 */
+    const double* sigma_abs;        /* num_lambda (DustMix::sectionAbs; sigma_ext = sigma_abs + sigma_sca was formed from it): read only by the
+                                       explicit-absorption photon cycle */
 } pmc_medium;
 
 typedef struct pmc_options
@@ -118,6 +120,9 @@ typedef struct pmc_options
     double  min_weight_reduction;   /* default 1e4 */
     int32_t min_scatt_events;       /* default 0 */
     double  path_length_bias;       /* default 0.5 */
+    int32_t explicit_absorption;    /* PhotonPacketOptions::explicitAbsorption: scattering and absorption optical depths apart, the packet
+                                       weight carries exp(-tau_abs) instead of the albedo (MonteCarloSimulation.cpp:568-569, 729-733, 751-766;
+                                       MediumSystem.cpp:905-932, 1075-1110) */
 } pmc_options;
 
 /* ---------------------------------------------------------------- source ---- */

@@ -605,7 +605,9 @@ namespace
     struct Segment
     {
         int m;
-        double ds, s, tau;
+        double ds, s, tau;   // tau: cumulative extinction optical depth -- or, in the explicit-absorption cycle, scattering optical depth
+        double tauAbs;       // cumulative absorption optical depth (explicit-absorption cycle), else zero (SpatialGridPath.hpp:98-108)
+        double tauExt() const { return tau + tauAbs; }
     };
 
     struct Packet
@@ -620,6 +622,7 @@ namespace
         double pathS{0};
         int interactionCell{-1};
         double interactionDistance{0};
+        double interactionOpticalDepth{0};   // cumulative absorption optical depth at the interaction point (explicit absorption)
         double luminosity() const { return W / lambda; }
     };
 
@@ -824,8 +827,28 @@ namespace
                 if (generator->ds > 0.)
                 {
                     pp.pathS += generator->ds;
-                    pp.segments.push_back(Segment{generator->m, generator->ds, pp.pathS, 0.});
+                    pp.segments.push_back(Segment{generator->m, generator->ds, pp.pathS, 0., 0.});
                 }
+            }
+            if (sc.options.explicit_absorption)
+            {
+                // MediumSystem::setScatteringAndAbsorptionOpticalDepths, single constant-section medium (MediumSystem.cpp:905-932)
+                double tauSca = 0., tauAbs = 0.;
+                const int ell = indexForLambda(pp.lambda);
+                const double sectionSca = sc.medium.sigma_sca[ell], sectionAbs = sc.medium.sigma_abs[ell];
+                for (auto& seg : pp.segments)
+                {
+                    if (seg.m >= 0)
+                    {
+                        double ns = sc.medium.number_density[seg.m] * seg.ds;
+                        tauSca += sectionSca * ns;
+                        tauAbs += sectionAbs * ns;
+                        counters.cell_visits++;
+                    }
+                    seg.tau = tauSca;
+                    seg.tauAbs = tauAbs;
+                }
+                return;
             }
             double tau = 0.;
             double section = sectionExt(pp.lambda);
@@ -869,7 +892,7 @@ namespace
             double extBeg = 1.;
             for (const auto& segment : pp.segments)
             {
-                double lnExtEnd = -segment.tau;
+                double lnExtEnd = -segment.tauExt();
                 double extEnd = exp(lnExtEnd);
                 int m = segment.m;
                 if (m >= 0)
@@ -915,6 +938,7 @@ namespace
             {
                 pp.interactionCell = -1;
                 pp.interactionDistance = 0.;
+                pp.interactionOpticalDepth = 0.;
                 return;
             }
             auto seg = std::upper_bound(segs.cbegin(), segs.cend(), tauinteract,
@@ -923,16 +947,19 @@ namespace
             {
                 pp.interactionCell = seg->m;
                 pp.interactionDistance = interpolateLinLin(tauinteract, 0., seg->tau, 0., seg->s);
+                pp.interactionOpticalDepth = interpolateLinLin(tauinteract, 0., seg->tau, 0., seg->tauAbs);
             }
             else if (seg < segs.cend())
             {
                 pp.interactionCell = seg->m;
                 pp.interactionDistance = interpolateLinLin(tauinteract, (seg - 1)->tau, seg->tau, (seg - 1)->s, seg->s);
+                pp.interactionOpticalDepth = interpolateLinLin(tauinteract, (seg - 1)->tau, seg->tau, (seg - 1)->tauAbs, seg->tauAbs);
             }
             else
             {
                 pp.interactionCell = (seg - 1)->m;
                 pp.interactionDistance = (seg - 1)->s;
+                pp.interactionOpticalDepth = (seg - 1)->tauAbs;
             }
         }
 
@@ -958,12 +985,21 @@ namespace
                 pp.W *= weight;
             }
             findInteractionPoint(pp, tau);
-            // MediumSystem::albedoForScattering (MediumSystem.cpp:678-693)
-            int m = pp.interactionCell;
-            double ksca = opacity(sc.medium.sigma_sca, pp.lambda, m);
-            double kext = opacity(sc.medium.sigma_ext, pp.lambda, m);
-            double albedo = kext > 0. ? ksca / kext : 0.;
-            pp.W *= (-expm1(-taupath) * albedo);
+            if (sc.options.explicit_absorption)
+            {
+                // MonteCarloSimulation.cpp:729-733: the escape fraction and the absorption along the way to the interaction point
+                double tauAbs = pp.interactionOpticalDepth;
+                pp.W *= (-expm1(-taupath) * exp(-tauAbs));
+            }
+            else
+            {
+                // MediumSystem::albedoForScattering (MediumSystem.cpp:678-693)
+                int m = pp.interactionCell;
+                double ksca = opacity(sc.medium.sigma_sca, pp.lambda, m);
+                double kext = opacity(sc.medium.sigma_ext, pp.lambda, m);
+                double albedo = kext > 0. ? ksca / kext : 0.;
+                pp.W *= (-expm1(-taupath) * albedo);
+            }
             // PhotonPacket::propagate (PhotonPacket.cpp:107-111)
             double s = pp.interactionDistance;
             pp.r.x += s * pp.k.x;
@@ -978,7 +1014,10 @@ namespace
             double tauinteract = -log(rng.uniform());  // Random::expon
             generator->start(pp.r, pp.k);
             counters.paths++;
-            double section = sectionExt(pp.lambda);
+            const bool explicitAbsorption = sc.options.explicit_absorption != 0;
+            const int ellmix = indexForLambda(pp.lambda);
+            // (explicit absorption: the interaction is drawn on the SCATTERING optical depth, MediumSystem.cpp:1075-1110)
+            double section = explicitAbsorption ? sc.medium.sigma_sca[ellmix] : sectionExt(pp.lambda);
             double tau = 0., s = 0.;
             bool found = false;
             while (generator->next())
@@ -1002,11 +1041,20 @@ namespace
                 }
             }
             if (!found) return false;
-            int m = pp.interactionCell;
-            double ksca = opacity(sc.medium.sigma_sca, pp.lambda, m);
-            double kext = opacity(sc.medium.sigma_ext, pp.lambda, m);
-            double albedo = kext > 0. ? ksca / kext : 0.;
-            pp.W *= albedo;
+            if (explicitAbsorption)
+            {
+                // MediumSystem.cpp:1105-1106 and MonteCarloSimulation.cpp:751-766
+                double tauAbs = tauinteract * sc.medium.sigma_abs[ellmix] / sc.medium.sigma_sca[ellmix];
+                pp.W *= exp(-tauAbs);
+            }
+            else
+            {
+                int m = pp.interactionCell;
+                double ksca = opacity(sc.medium.sigma_sca, pp.lambda, m);
+                double kext = opacity(sc.medium.sigma_ext, pp.lambda, m);
+                double albedo = kext > 0. ? ksca / kext : 0.;
+                pp.W *= albedo;
+            }
             double sd = pp.interactionDistance;
             pp.r.x += sd * pp.k.x;
             pp.r.y += sd * pp.k.y;

@@ -476,6 +476,7 @@ namespace
                           &A.nint, &A.dustExt, &A.dustSca, &A.dustAsym};
         for (double** d : dbl)
             if ((rc = ctx->allocate<double>(n, d, false, &own))) return rc;
+        if (ctx->dev.explicit_absorption && (rc = ctx->allocate<double>(n, &A.dustAbs, false, &own))) return rc;
         if ((rc = ctx->allocate<uint64_t>(n, &A.history, false, &own))) return rc;
         if ((rc = ctx->allocate<uint32_t>(n, &A.rngBlock, false, &own))) return rc;
         int32_t** ints[] = {&A.mode, &A.nscatt, &A.mint};
@@ -830,6 +831,13 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     if ((rc = ctx->upload(med.sigma_ext, med.num_lambda, &D.sigma_ext))) return bail(rc);
     if ((rc = ctx->upload(med.sigma_sca, med.num_lambda, &D.sigma_sca))) return bail(rc);
     if ((rc = ctx->upload(med.asymmpar, med.num_lambda, &D.asymmpar))) return bail(rc);
+    D.explicit_absorption = scene->options.explicit_absorption ? 1 : 0;
+    D.sigma_abs = nullptr;
+    if (D.explicit_absorption)
+    {
+        if (!med.sigma_abs) return bail(fail(PMC_ERR_INVALID, "explicit absorption needs pmc_medium::sigma_abs"));
+        if ((rc = ctx->upload(med.sigma_abs, med.num_lambda, &D.sigma_abs))) return bail(rc);
+    }
     int walkDoubles = D.lds_grid_len;   // walk kernels and cycle start kernel: the grid tables, at offset 0
     int transDoubles = 0;               // transition and launch kernels: no grid tables
     int launchOnlyDoubles = 0;          // what only the launch kernel stages, behind the regions the two kernels share
@@ -901,7 +909,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     D.mono = (sourceOf(0).lambda_mode == PMC_LAMBDA_OLIGO && getenv("PMC_NO_MONO") == nullptr) ? 1 : 0;
     for (int si = 0; si < numSources && D.mono; ++si)
         if (sourceOf(si).num_oligo != 1 || sourceOf(si).oligo_lambda[0] != sourceOf(0).oligo_lambda[0]) D.mono = 0;
-    D.mono_lambda = D.mono_ext = D.mono_sca = D.mono_asym = 0.;
+    D.mono_lambda = D.mono_ext = D.mono_sca = D.mono_asym = D.mono_abs = 0.;
     if (D.mono)
     {
         const double lambda = sourceOf(0).oligo_lambda[0];
@@ -921,6 +929,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         }
         D.mono_lambda = lambda;
         D.mono_ext = med.sigma_ext[il], D.mono_sca = med.sigma_sca[il], D.mono_asym = med.asymmpar[il];
+        if (D.explicit_absorption) D.mono_abs = med.sigma_abs[il];
     }
 
     // ---- instruments and frame layout
@@ -1316,12 +1325,12 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 HIP_TRY(hipEventRecord(ctx->evJoin[g], sp));
                 RfLogArgs log = {ctx->rfKeys[g][0], ctx->rfVals[g][0], rfLogged ? ctx->rfCap[g] : 0ull, PMC_CTR_RFLOG(g), rfPadKey};
                 if (serialWalks) HIP_TRY(hipEventRecord(ctx->evProp[g], sg));  // (in series: the propagation kernel starts where the peel-off kernels end)
-                HIP_TRY(pmcLaunchProp(ctx->slot, ctx->wide, D.rf_store, base[g], numTasks, list, PMC_CTR_TASK(g, 0), seed, propGrid, ctx->walkLds, &log, sg));
+                HIP_TRY(pmcLaunchProp(ctx->slot, ctx->wide, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0), base[g], numTasks, list, PMC_CTR_TASK(g, 0), seed, propGrid, ctx->walkLds, &log, sg));
                 if (!serialWalks) HIP_TRY(hipEventRecord(ctx->evProp[g], sg));
                 HIP_TRY(hipStreamWaitEvent(sg, ctx->evJoin[g], 0));
             }
             else
-                HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, D.rf_store, base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->block,
+                HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0), base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->block,
                                       ctx->walkLds, sg));
             haveWalk[g] = true;
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));

@@ -114,6 +114,7 @@ struct SlotArrays
     double*  rngSpare;
     uint32_t* rngBlock;                     // (block << 1) | have
     double* dustExt; double* dustSca;       // extinction and scattering cross section of the dust mix at the history's wavelength
+    double* dustAbs;                        // (explicit-absorption cycle only, else null) its absorption cross section
     double* dustAsym;                       // and its asymmetry parameter: DustMix::indexForLambda(lambda) is looked up ONCE, at launch
     int32_t* mode;                          // bit 5 alive, bits 8-23 observers (group leaders) with a peel-off packet this cycle
     int32_t* nscatt;
@@ -249,14 +250,16 @@ struct DevScene
     const double* lambda_border;
     const double* sigma_ext;
     const double* sigma_sca;
+    const double* sigma_abs;     // (explicit-absorption cycle only, else null)
     const double* asymmpar;
     // every source emits at ONE wavelength, the same one (oligochromatic with a single wavelength: BASELINE configs[0] and [1]): the
     // wavelength of a history and the dust mix's properties at it are constants of the scene, and no kernel stores or loads them per
     // slot (SlotArrays::lambda, dustExt, dustSca, dustAsym stay unused)
     int32_t mono;
-    double mono_lambda, mono_ext, mono_sca, mono_asym;
+    double mono_lambda, mono_ext, mono_sca, mono_asym, mono_abs;
     // ---- options
     int32_t force_scattering;
+    int32_t explicit_absorption;  // PhotonPacketOptions::explicitAbsorption (pmc.h pmc_options)
     double  min_weight_reduction;
     int32_t min_scatt_events;
     double  path_length_bias;

@@ -268,24 +268,32 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
                {reinterpret_cast<const void*>(&walkPeelKernel<true>), walkMax},
                {reinterpret_cast<const void*>(&walkPeelKernel2<false>), std::min(walkMax + 16 + pmcPeelQueueBytes(), size_t(160) * 1024)},
                {reinterpret_cast<const void*>(&walkPeelKernel2<true>), std::min(walkMax + 16 + pmcPeelQueueBytes(), size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPropKernel<false, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPropKernel<false, true>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPropKernel<true, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPropKernel<true, true>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, false, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, true, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, false, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, true, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, false, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, true, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, false, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, true, true>), walkMax},
                {reinterpret_cast<const void*>(&traceTreeKernel<false, false>), walkMax},
                {reinterpret_cast<const void*>(&traceTreeKernel<false, true>), walkMax},
                {reinterpret_cast<const void*>(&traceTreeKernel<true, false>), walkMax},
                {reinterpret_cast<const void*>(&traceTreeKernel<true, true>), walkMax},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, false>), walkMax},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, false, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, true, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, false, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, true, true>), walkMax},
                {reinterpret_cast<const void*>(&traceRayKernel<GRID_CART>), walkMax},
                {reinterpret_cast<const void*>(&transitionKernel), transitionMax},
                {reinterpret_cast<const void*>(&launchKernel), transitionMax},
                {reinterpret_cast<const void*>(&cycleStartKernel<GRID_TREE>), walkMax},
                {reinterpret_cast<const void*>(&cycleStartKernel<GRID_CART>), walkMax},
                {reinterpret_cast<const void*>(&cycleStartKernel<GRID_VORO>), walkMax},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false>), walkMax},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, true, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, true, true>), walkMax},
                {reinterpret_cast<const void*>(&traceRayKernel<GRID_VORO>), walkMax}};
     for (const auto& k : all)
     {
@@ -309,13 +317,13 @@ extern "C" int pmcWalkBlocksPerCU(int gridKind, int kind, int wide, int block, s
         // (with the pass-1 records of pmcLaunchProp)
         const size_t trimOffset = (ldsBytes + 15) & ~size_t(15);
         if (!getenv("PMC_PROP_NO_TRIM") && trimOffset + PROP_TRIM_BYTES <= size_t(160) * 1024) ldsBytes = trimOffset + PROP_TRIM_BYTES;
-        e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<true, false>), block, ldsBytes)
-                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<false, false>), block, ldsBytes);
+        e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<true, false, false>), block, ldsBytes)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<false, false, false>), block, ldsBytes);
     }
     else if (gridKind == PMC_GRID_VORONOI)
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false>), block, ldsBytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, false>), block, ldsBytes);
     else
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_CART, false>), block, ldsBytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_CART, false, false>), block, ldsBytes);
     return e == hipSuccess ? n : 0;
 }
 
@@ -334,9 +342,12 @@ extern "C" int pmcPropBlock(void)
 extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int taskBase, int numTaskRecords, int taskCounter,
                                     uint64_t seed, int grid, int block, size_t ldsBytes, hipStream_t stream)
 {
-    // (the radiation-field flavour is a separate instantiation: the plain photon loop pays nothing for it)
-    auto kernel = gridKind == PMC_GRID_VORONOI ? (storeRf ? walkKernel<GRID_VORO, true> : walkKernel<GRID_VORO, false>)
-                                               : (storeRf ? walkKernel<GRID_CART, true> : walkKernel<GRID_CART, false>);
+    // (the radiation-field and the explicit-absorption flavours are separate instantiations: the plain photon loop pays nothing for
+    // them; storeRf: bit 0 = the radiation field is stored, bit 1 = explicit absorption)
+    const bool rf = (storeRf & 1) != 0, ea = (storeRf & 2) != 0;
+    auto kernel = gridKind == PMC_GRID_VORONOI
+                      ? (ea ? (rf ? walkKernel<GRID_VORO, true, true> : walkKernel<GRID_VORO, false, true>) : (rf ? walkKernel<GRID_VORO, true, false> : walkKernel<GRID_VORO, false, false>))
+                      : (ea ? (rf ? walkKernel<GRID_CART, true, true> : walkKernel<GRID_CART, false, true>) : (rf ? walkKernel<GRID_CART, true, false> : walkKernel<GRID_CART, false, false>));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter, seed);
     return hipGetLastError();
 }
@@ -367,12 +378,14 @@ extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlo
 extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, const int* list, int cursor, uint64_t seed, int grid,
                                     size_t ldsBytes, const RfLogArgs* rfLog, hipStream_t stream)
 {
-    auto kernel = wide ? (storeRf ? walkPropKernel<true, true> : walkPropKernel<true, false>)
-                       : (storeRf ? walkPropKernel<false, true> : walkPropKernel<false, false>);
+    // (storeRf: bit 0 = the radiation field is stored, bit 1 = explicit absorption)
+    const bool rf = (storeRf & 1) != 0, ea = (storeRf & 2) != 0;
+    auto kernel = wide ? (ea ? (rf ? walkPropKernel<true, true, true> : walkPropKernel<true, false, true>) : (rf ? walkPropKernel<true, true, false> : walkPropKernel<true, false, false>))
+                       : (ea ? (rf ? walkPropKernel<false, true, true> : walkPropKernel<false, false, true>) : (rf ? walkPropKernel<false, true, false> : walkPropKernel<false, false, false>));
     // (the pass-1 records follow the grid tables in LDS, if there is room)
     static const bool noTrim = getenv("PMC_PROP_NO_TRIM") != nullptr;  // (tuning aid)
     const size_t trimOffset = (ldsBytes + 15) & ~size_t(15);
-    const bool trim = !noTrim && trimOffset + PROP_TRIM_BYTES <= size_t(160) * 1024;
+    const bool trim = !noTrim && !ea && trimOffset + PROP_TRIM_BYTES <= size_t(160) * 1024;
     RfLogArgs none = {nullptr, nullptr, 0ull, 0, 0u};
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PROP_BLOCK), trim ? trimOffset + PROP_TRIM_BYTES : ldsBytes, stream, slot, slotBase, numSlots, cursor,
                        seed, trim ? (int)trimOffset : -1, rfLog ? *rfLog : none, list);

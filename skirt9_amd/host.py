@@ -49,7 +49,8 @@ class Grid(C.Structure):
 class Medium(C.Structure):
     _fields_ = [("number_density", C.POINTER(C.c_double)), ("num_lambda", C.c_int32),
                 ("lambda_border", C.POINTER(C.c_double)), ("sigma_ext", C.POINTER(C.c_double)),
-                ("sigma_sca", C.POINTER(C.c_double)), ("asymmpar", C.POINTER(C.c_double))]
+                ("sigma_sca", C.POINTER(C.c_double)), ("asymmpar", C.POINTER(C.c_double)),
+                ("sigma_abs", C.POINTER(C.c_double))]
 
 
 class SceneHead(C.Structure):

@@ -93,6 +93,7 @@ namespace
         f(m.sigma_ext, size_t(m.num_lambda));
         f(m.sigma_sca, size_t(m.num_lambda));
         f(m.asymmpar, size_t(m.num_lambda));
+        f(m.sigma_abs, size_t(m.num_lambda));
         visitSource(s.source, f);
         f(s.instruments, size_t(s.num_instruments));
         for (int i = 0; i < s.num_instruments; ++i)

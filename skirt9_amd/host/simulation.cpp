@@ -370,9 +370,10 @@ namespace skh
         _options.min_weight_reduction = 1e4;
         _options.min_scatt_events = 0;
         _options.path_length_bias = 0.5;
+        _options.explicit_absorption = 0;
         if (const XmlElement* po = ms->item("photonPacketOptions"))
         {
-            if (rd.boolean(*po, "explicitAbsorption", false)) unsupported("explicitAbsorption");
+            _options.explicit_absorption = rd.boolean(*po, "explicitAbsorption", false) ? 1 : 0;
             _options.force_scattering = rd.boolean(*po, "forceScattering", true);
             _options.min_weight_reduction = rd.number(*po, "minWeightReduction", "1e4");
             _options.min_scatt_events = rd.integer(*po, "minScattEvents", 0);
@@ -994,6 +995,7 @@ namespace skh
         m.lambda_border = _medium->mix->lambdaBorder.data();
         m.sigma_ext = _medium->mix->sigmaExt.data();
         m.sigma_sca = _medium->mix->sigmaSca.data();
+        m.sigma_abs = _medium->mix->sigmaAbs.data();
         m.asymmpar = _medium->mix->asymmpar.data();
 
         _scene.options = _options;

@@ -21,6 +21,9 @@ Fixtures:
   cfg1file_*   config 1 with MeanFileDustMix (tests/ski/cfg1file.ski + cfg1file_dust.txt): 10^5 packets -> files
   cfg1rf_*, cfg3rf_*   config 1 and reduced config 3 with storeRadiationField and a RadiationFieldProbe (PerCellForm):
                the probe file <name>_rf_J.dat (gzip) and the SED files
+  cfg2ea_*, cfg1nfea_*, cfg1rfea_*   the photon cycle with explicitAbsorption="true" (MonteCarloSimulation.cpp:568-569, 729-733, 751-766;
+               MediumSystem.cpp:905-975, 1075-1110): reduced config 2 (forced scattering), the non-forced variant of config 1, and config 1 with
+               the radiation field stored (probe file, gzip)
   cfg5small_*  reduced config 5 (tests/ski/cfg5small.ski): Voronoi grid with 1500 random sites, panchromatic, four
                instruments -> files, rays, cells (the host layer's tessellation is its own: the traversal is compared bit
                for bit, cell volumes to rounding, sampled densities and output files statistically)
@@ -130,7 +133,7 @@ def main():
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
     for name, scale in (("cfg1", 3.08567758e16), ("cfg1mesh", 3.08567758e16), ("cfg1mesh2", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg2deep", 300 * 3.08567758e16), ("cfg2deeper", 100 * 3.08567758e16), ("cfg3small", None), ("cfg3z", None), ("cfg1nf", None), ("cfg2nf", None),
-                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1sed", None), ("cfg3sed", None), ("cfg3norm", "sed"), ("cfg3disk", "sed"), ("cfg3multi", "sed"), ("cfg3ten", "sed"), ("cfg3flat", "sed"), ("cfg3off", "sed"), ("cfg3plum", "sed"), ("cfg1rf", "rf"), ("cfg3rf", "rf"),
+                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1sed", None), ("cfg3sed", None), ("cfg3norm", "sed"), ("cfg3disk", "sed"), ("cfg3multi", "sed"), ("cfg3ten", "sed"), ("cfg3flat", "sed"), ("cfg3off", "sed"), ("cfg3plum", "sed"), ("cfg1rf", "rf"), ("cfg3rf", "rf"), ("cfg2ea", None), ("cfg1nfea", None), ("cfg1rfea", "rf"),
                         ("cfg5small", 4000 * 3.08567758e16), ("cfg5dd", "cells"), ("cfg2shell", "cells"), ("cfg2torus", "cells"), ("cfg2ring", "cells"), ("cfg1list", "cells")):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue

@@ -83,7 +83,7 @@ def _compare_frames(sim, gpu, ref, n):
             assert a[:lay.num_lambda].sum() == n
 
 
-@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg2nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg3file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg3ten.ski", 20000), ("cfg3twelve.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg1long.ski", 5000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000), ("cfg2deep.ski", 20000), ("cfg2deeper.ski", 20000)])
+@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg2nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg3file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg3ten.ski", 20000), ("cfg3twelve.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg1long.ski", 5000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000), ("cfg2deep.ski", 20000), ("cfg2deeper.ski", 20000), ("cfg2ea.ski", 20000), ("cfg1nfea.ski", 50000)])
 def test_photon_loop_matches_oracle(name, n):
     sim = Simulation(ski(name), num_packets=n).setup()
     eng = _engine(sim)
@@ -95,6 +95,35 @@ def test_photon_loop_matches_oracle(name, n):
     assert c["histories"] == n
     assert c["stat_overflows"] == 0
     # identical histories => identical amounts of work (allow a handful of last-bit decision flips)
+    assert abs(c["cell_visits"] - counters.cell_visits) <= 1e-4 * counters.cell_visits
+    assert abs(c["scatterings"] - counters.scatterings) <= 1e-4 * counters.scatterings + 2
+    _compare_frames(sim, gpu, ref, n)
+
+
+@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg3small.ski", 20000), ("cfg5small.ski", 20000), ("cfg2deep.ski", 20000), ("cfg2nf.ski", 50000),
+                                    ("cfg3ten.ski", 20000)])
+def test_explicit_absorption_matches_oracle(name, n, tmp_path):
+    """PhotonPacketOptions::explicitAbsorption (MonteCarloSimulation.cpp:568-569, 729-733, 751-766; MediumSystem.cpp:905-932, 1075-1110): the
+    scenes of the parity list with explicitAbsorption="true" -- Cartesian, octree (incl. the 21-bit index variant and the non-forced
+    cycle), Voronoi, panchromatic (the absorption cross section travels in the slot) and a ten-source system -- HIP engine against
+    the oracle, which the reference's own files pin on cfg2ea / cfg1nfea / cfg1rfea (test_oracle_golden.py)"""
+    import shutil
+    text = open(ski(name)).read()
+    assert 'explicitAbsorption="false"' in text
+    for f in os.listdir(os.path.dirname(ski(name))):
+        if f.endswith(".txt"):
+            shutil.copy(ski(f), tmp_path / f)   # (input files named in a ski file are read from its directory)
+    path = tmp_path / name.replace(".ski", "ea.ski")
+    path.write_text(text.replace('explicitAbsorption="false"', 'explicitAbsorption="true"'))
+    sim = Simulation(str(path), num_packets=n).setup()
+    eng = _engine(sim)
+    eng.run_primary(0, n, 777)
+    gpu = eng.download()
+    ref, counters = O.run_primary(sim, 0, n, O.RNG_PHILOX, seed=777)
+    plain, _ = O.run_primary(Simulation(ski(name), num_packets=n).setup(), 0, n, O.RNG_PHILOX, seed=777)
+    assert abs(plain.sum() - ref.sum()) > 1e-6 * np.abs(ref).sum()      # (the cycle changes the weights: not the same numbers)
+    c = eng.counters()
+    assert c["histories"] == n and c["stat_overflows"] == 0
     assert abs(c["cell_visits"] - counters.cell_visits) <= 1e-4 * counters.cell_visits
     assert abs(c["scatterings"] - counters.scatterings) <= 1e-4 * counters.scatterings + 2
     _compare_frames(sim, gpu, ref, n)
@@ -165,7 +194,7 @@ def test_fits_output_from_gpu(tmp_path):
     assert abs(sed[2] - 2.943198361e-06) < 1e-9 * 2.94e-06 + 5 * 4e-3 * 2.94e-06
 
 
-@pytest.mark.parametrize("name,n", [("cfg1rf.ski", 20000), ("cfg3rf.ski", 20000)])
+@pytest.mark.parametrize("name,n", [("cfg1rf.ski", 20000), ("cfg3rf.ski", 20000), ("cfg1rfea.ski", 20000), ("cfg3rfea.ski", 20000)])
 def test_radiation_field_matches_oracle(name, n):
     """storeRadiationField on the GPU (walk kernel flavour RF: L * lnmean(e^-tau0, e^-tau1) * ds per path segment, f64
     atomics into rf[m * nbins + ell]) against the oracle following the same Philox histories: totals to 1e-9, cells

@@ -17,7 +17,7 @@ from skirt9_amd.host import Grid, Medium, SceneHead, scene_head  # noqa: E402,F4
 def test_cell_densities_bit_exact(name, cells, nodes):
     sim = Simulation(ski(name + ".ski")).setup()
     head = scene_head(sim)
-    assert head.abi_version == 6
+    assert head.abi_version == 7
     assert head.grid.num_cells == cells
     if nodes:
         assert head.grid.kind == 2 and head.grid.num_nodes == nodes
@@ -324,11 +324,15 @@ def test_list_mesh_bit_exact():
 
 # ---------------------------------------------------------------- tabulated source spectra
 
-class SourceHead(C.Structure):
-    """pmc_options + the leading members of pmc_source that follow pmc_medium in pmc_scene (include/pmc.h)"""
+class Options(C.Structure):
+    """pmc_options (include/pmc.h)"""
     _fields_ = [("force_scattering", C.c_int32), ("min_weight_reduction", C.c_double), ("min_scatt_events", C.c_int32),
-                ("path_length_bias", C.c_double),
-                ("kind", C.c_int32), ("position", C.c_double * 3), ("reff", C.c_double), ("sersic_n", C.c_int32),
+                ("path_length_bias", C.c_double), ("explicit_absorption", C.c_int32)]
+
+
+class SourceHead(C.Structure):
+    """the leading members of pmc_source, which follows pmc_medium and pmc_options in pmc_scene (include/pmc.h)"""
+    _fields_ = [("kind", C.c_int32), ("position", C.c_double * 3), ("reff", C.c_double), ("sersic_n", C.c_int32),
                 ("sersic_s", C.POINTER(C.c_double)), ("sersic_M", C.POINTER(C.c_double)), ("box", C.c_double * 6),
                 ("packet_luminosity", C.c_double), ("lambda_mode", C.c_int32), ("num_oligo", C.c_int32),
                 ("oligo_lambda", C.POINTER(C.c_double)), ("oligo_weight", C.POINTER(C.c_double)), ("lambda_bias", C.c_double),
@@ -337,7 +341,7 @@ class SourceHead(C.Structure):
 
 
 class SceneWithSource(C.Structure):
-    _fields_ = [("abi_version", C.c_int32), ("grid", Grid), ("medium", Medium), ("src", SourceHead)]
+    _fields_ = [("abi_version", C.c_int32), ("grid", Grid), ("medium", Medium), ("options", Options), ("src", SourceHead)]
 
 
 def _sed_tables(sim):
