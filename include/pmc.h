@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 7
+#define PMC_ABI_VERSION 8
 
 enum { PMC_OK = 0, PMC_ERR_INVALID = -1, PMC_ERR_UNSUPPORTED = -2, PMC_ERR_DEVICE = -3, PMC_ERR_NOMEM = -4,
        PMC_ERR_OVERFLOW = -5 /* the pool of statistics-list blocks ran out during the segment (see pmc_run_primary) */ };
@@ -100,9 +100,11 @@ typedef struct pmc_grid
 
 /* ---------------------------------------------------------------- medium ---- */
 
+#define PMC_MAX_MEDIA 4
 typedef struct pmc_medium
 {
-    /* one dust medium with spatially constant cross sections (Configuration::hasSingleConstantSectionMedium) */
+    /* one dust medium component with spatially constant cross sections (Configuration::hasSingleConstantSectionMedium; several of
+       them: hasMultipleConstantSectionMedia, see pmc_scene::media) */
     const double* number_density;   /* n[m], num_cells (MediumState, MediumSystem.cpp:868) */
     /* DustMix tables (DustMix.cpp:93-98,112-162): index = locateClip(lambda_border, lambda) */
     int32_t       num_lambda;
@@ -246,6 +248,13 @@ typedef struct pmc_scene
     int32_t         num_sources;
     const pmc_source* sources;
     const uint64_t*  source_first;
+    /* a medium system with more than one component (MediumSystem.cpp:874-887 optical depths summed over the components in order,
+       :678-730 albedo and scattering weights from the components' scattering opacities in the interaction cell, :796-817 the
+       scattering component drawn from their cumulative distribution with ONE uniform deviate, :734-767 consolidated peel-off).
+       num_media <= 1: `medium` above is the only component.  num_media > 1: media[0..num_media) replace it (each with its own cell
+       densities and dust tables).  At most PMC_MAX_MEDIA components. */
+    int32_t           num_media;
+    const pmc_medium* media;
 } pmc_scene;
 
 /* counted work, accumulated over all pmc_run_primary calls since create/reset (roofline inputs) */

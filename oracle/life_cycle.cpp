@@ -666,6 +666,16 @@ namespace
         }
 
         // DustMix::indexForLambda / sectionExt / ... (DustMix.cpp:276-279,319-367)
+        // several medium components with constant cross sections (Configuration::hasMultipleConstantSectionMedia)
+        int numMedia() const { return sc.num_media > 1 ? sc.num_media : 1; }
+        const pmc_medium& med(int h) const { return sc.num_media > 1 ? sc.media[h] : sc.medium; }
+        int indexForLambda(int h, double lambda) const { return locateClip(med(h).lambda_border, med(h).num_lambda, lambda); }
+        // opacity of component h in cell m (MaterialMix::opacitySca / opacityExt: n sigma)
+        double opacityOf(int h, const double* sigma, double lambda, int m) const
+        {
+            double n = med(h).number_density[m];
+            return n > 0. ? n * sigma[indexForLambda(h, lambda)] : 0.;
+        }
         int indexForLambda(double lambda) const { return locateClip(sc.medium.lambda_border, sc.medium.num_lambda, lambda); }
         double sectionExt(double lambda) const { return sc.medium.sigma_ext[indexForLambda(lambda)]; }
         double opacity(const double* sigma, double lambda, int m) const
@@ -830,6 +840,39 @@ namespace
                     pp.segments.push_back(Segment{generator->m, generator->ds, pp.pathS, 0., 0.});
                 }
             }
+            if (numMedia() > 1)
+            {
+                // several components: MediumSystem.cpp:874-887 (extinction), :934-955 (scattering and absorption apart)
+                const int H = numMedia();
+                double sext[PMC_MAX_MEDIA], ssca[PMC_MAX_MEDIA], sabs[PMC_MAX_MEDIA];
+                for (int h = 0; h != H; ++h)
+                {
+                    const int ell = indexForLambda(h, pp.lambda);
+                    sext[h] = med(h).sigma_ext[ell], ssca[h] = med(h).sigma_sca[ell], sabs[h] = med(h).sigma_abs[ell];
+                }
+                double tau = 0., tauSca = 0., tauAbs = 0.;
+                for (auto& seg : pp.segments)
+                {
+                    if (seg.m >= 0)
+                    {
+                        counters.cell_visits++;
+                        for (int h = 0; h != H; ++h)
+                        {
+                            if (sc.options.explicit_absorption)
+                            {
+                                double ns = med(h).number_density[seg.m] * seg.ds;
+                                tauSca += ssca[h] * ns;
+                                tauAbs += sabs[h] * ns;
+                            }
+                            else
+                                tau += sext[h] * med(h).number_density[seg.m] * seg.ds;
+                        }
+                    }
+                    seg.tau = sc.options.explicit_absorption ? tauSca : tau;
+                    seg.tauAbs = tauAbs;
+                }
+                return;
+            }
             if (sc.options.explicit_absorption)
             {
                 // MediumSystem::setScatteringAndAbsorptionOpticalDepths, single constant-section medium (MediumSystem.cpp:905-932)
@@ -915,6 +958,27 @@ namespace
             generator->start(pp.r, pp.k);
             counters.paths++;
             double tau = 0., s = 0.;
+            if (numMedia() > 1)
+            {
+                // MediumSystem.cpp:1225-1242
+                const int H = numMedia();
+                double sectionv[PMC_MAX_MEDIA];
+                for (int h = 0; h != H; ++h) sectionv[h] = med(h).sigma_ext[indexForLambda(h, pp.lambda)];
+                while (generator->next())
+                {
+                    double ds = generator->ds;
+                    int m = generator->m;
+                    if (m >= 0)
+                    {
+                        counters.cell_visits++;
+                        for (int h = 0; h != H; ++h) tau += sectionv[h] * med(h).number_density[m] * ds;
+                        if (tau >= taumax) return std::numeric_limits<double>::infinity();
+                    }
+                    s += ds;
+                    if (s > distance) break;
+                }
+                return tau;
+            }
             double section = sectionExt(pp.lambda);
             while (generator->next())
             {
@@ -963,6 +1027,20 @@ namespace
             }
         }
 
+        // ---- MediumSystem::albedoForScattering (MediumSystem.cpp:678-693): scattering over extinction opacity of all components in the
+        //      interaction cell
+        double albedoForScattering(const Packet& pp) const
+        {
+            int m = pp.interactionCell;
+            double ksca = 0., kext = 0.;
+            for (int h = 0; h != numMedia(); ++h)
+            {
+                ksca += opacityOf(h, med(h).sigma_sca, pp.lambda, m);
+                kext += opacityOf(h, med(h).sigma_ext, pp.lambda, m);
+            }
+            return kext > 0. ? ksca / kext : 0.;
+        }
+
         // ---- MonteCarloSimulation::simulateForcedPropagation (MonteCarloSimulation.cpp:696-742)
         void simulateForcedPropagation(Packet& pp)
         {
@@ -994,11 +1072,7 @@ namespace
             else
             {
                 // MediumSystem::albedoForScattering (MediumSystem.cpp:678-693)
-                int m = pp.interactionCell;
-                double ksca = opacity(sc.medium.sigma_sca, pp.lambda, m);
-                double kext = opacity(sc.medium.sigma_ext, pp.lambda, m);
-                double albedo = kext > 0. ? ksca / kext : 0.;
-                pp.W *= (-expm1(-taupath) * albedo);
+                pp.W *= (-expm1(-taupath) * albedoForScattering(pp));
             }
             // PhotonPacket::propagate (PhotonPacket.cpp:107-111)
             double s = pp.interactionDistance;
@@ -1015,6 +1089,56 @@ namespace
             generator->start(pp.r, pp.k);
             counters.paths++;
             const bool explicitAbsorption = sc.options.explicit_absorption != 0;
+            if (numMedia() > 1)
+            {
+                // several components: MediumSystem.cpp:1013-1037 (extinction), :1112-1153 (scattering and absorption apart)
+                const int H = numMedia();
+                double sext[PMC_MAX_MEDIA], ssca[PMC_MAX_MEDIA], sabs[PMC_MAX_MEDIA];
+                for (int h = 0; h != H; ++h)
+                {
+                    const int ell = indexForLambda(h, pp.lambda);
+                    sext[h] = med(h).sigma_ext[ell], ssca[h] = med(h).sigma_sca[ell], sabs[h] = med(h).sigma_abs[ell];
+                }
+                double tau = 0., tauAbs = 0., s = 0.;
+                while (generator->next())
+                {
+                    double tau0 = tau, tauAbs0 = tauAbs, s0 = s;
+                    double ds = generator->ds;
+                    int m = generator->m;
+                    if (m >= 0)
+                    {
+                        counters.cell_visits++;
+                        for (int h = 0; h != H; ++h)
+                        {
+                            if (explicitAbsorption)
+                            {
+                                double ns = med(h).number_density[m] * ds;
+                                tau += ssca[h] * ns;
+                                tauAbs += sabs[h] * ns;
+                            }
+                            else
+                                tau += sext[h] * med(h).number_density[m] * ds;
+                        }
+                    }
+                    s += ds;
+                    if (tauinteract < tau)
+                    {
+                        pp.interactionCell = m;
+                        pp.interactionDistance = interpolateLinLin(tauinteract, tau0, tau, s0, s);
+                        if (explicitAbsorption)
+                            pp.W *= exp(-interpolateLinLin(tauinteract, tau0, tau, tauAbs0, tauAbs));
+                        else
+                            pp.W *= albedoForScattering(pp);
+                        double sd = pp.interactionDistance;
+                        pp.r.x += sd * pp.k.x;
+                        pp.r.y += sd * pp.k.y;
+                        pp.r.z += sd * pp.k.z;
+                        pp.D += sd;
+                        return true;
+                    }
+                }
+                return false;
+            }
             const int ellmix = indexForLambda(pp.lambda);
             // (explicit absorption: the interaction is drawn on the SCATTERING optical depth, MediumSystem.cpp:1075-1110)
             double section = explicitAbsorption ? sc.medium.sigma_sca[ellmix] : sectionExt(pp.lambda);
@@ -1049,11 +1173,7 @@ namespace
             }
             else
             {
-                int m = pp.interactionCell;
-                double ksca = opacity(sc.medium.sigma_sca, pp.lambda, m);
-                double kext = opacity(sc.medium.sigma_ext, pp.lambda, m);
-                double albedo = kext > 0. ? ksca / kext : 0.;
-                pp.W *= albedo;
+                pp.W *= albedoForScattering(pp);
             }
             double sd = pp.interactionDistance;
             pp.r.x += sd * pp.k.x;
@@ -1251,6 +1371,21 @@ namespace
         void peelOffScattering(const Packet& pp, Packet& ppp)
         {
             double lambda = pp.lambda;
+            // MediumSystem::weightsForScattering (MediumSystem.cpp:697-730): the components' shares of the scattering opacity in the
+            // interaction cell; no peel-off at all if none of them scatters
+            const int H = numMedia();
+            double wv[PMC_MAX_MEDIA] = {1., 0., 0., 0.};
+            if (H > 1)
+            {
+                double sum = 0.;
+                for (int h = 0; h != H; ++h)
+                {
+                    wv[h] = opacityOf(h, med(h).sigma_sca, lambda, pp.interactionCell);
+                    sum += wv[h];
+                }
+                if (!(sum > 0.)) return;
+                for (int h = 0; h != H; ++h) wv[h] /= sum;
+            }
             for (int i = 0; i < sc.num_instruments; ++i)
             {
                 const pmc_instrument& ins = sc.instruments[i];
@@ -1258,10 +1393,17 @@ namespace
                 {
                     V3 k{ins.kobs[0], ins.kobs[1], ins.kobs[2]};
                     double costheta = pp.k.x * k.x + pp.k.y * k.y + pp.k.z * k.z;
-                    double g = sc.medium.asymmpar[indexForLambda(lambda)];
-                    double value = std::abs(g) > 0.95 ? meanHG(g, costheta) : valueHG(g, costheta);
                     double I = 0.;
-                    I += value * 1.;
+                    for (int h = 0; h != H; ++h)
+                    {
+                        // (MediumSystem.cpp:745-757: components that do not scatter the packet are skipped)
+                        if (wv[h] > 0.)
+                        {
+                            double g = med(h).asymmpar[indexForLambda(h, lambda)];
+                            double value = std::abs(g) > 0.95 ? meanHG(g, costheta) : valueHG(g, costheta);
+                            I += value * wv[h];
+                        }
+                    }
                     ppp.lambda = lambda;
                     ppp.W = pp.W * I;
                     ppp.D = pp.D - (k.x * pp.r.x + k.y * pp.r.y + k.z * pp.r.z);
@@ -1279,7 +1421,20 @@ namespace
         //      DustMix.cpp:490-511, PhotonPacket.cpp:115-122)
         void simulateScattering(Packet& pp)
         {
-            double g = sc.medium.asymmpar[indexForLambda(pp.lambda)];
+            // the scattering component, drawn from the cumulative distribution of the components' scattering opacities in the
+            // interaction cell with ONE uniform deviate (MediumSystem.cpp:806-817, NR::cdf, NR::locateClip)
+            int hpick = 0;
+            if (numMedia() > 1)
+            {
+                const int H = numMedia();
+                double Xv[PMC_MAX_MEDIA + 1];
+                Xv[0] = 0.;
+                for (int h = 0; h != H; ++h) Xv[h + 1] = Xv[h] + opacityOf(h, med(h).sigma_sca, pp.lambda, pp.interactionCell);
+                double norm = Xv[H];
+                for (int h = 0; h <= H; ++h) Xv[h] /= norm;
+                hpick = locateClip(Xv, H + 1, rng.uniform());
+            }
+            double g = med(hpick).asymmpar[indexForLambda(hpick, pp.lambda)];
             V3 knew;
             if (fabs(g) < 1e-6)
                 knew = randomDirection(rng);

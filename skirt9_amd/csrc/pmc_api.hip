@@ -603,6 +603,8 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     if (!scene || !out) return fail(PMC_ERR_INVALID, "null argument");
     *out = nullptr;
     if (scene->abi_version != PMC_ABI_VERSION) return fail(PMC_ERR_INVALID, "pmc_scene ABI version mismatch");
+    if (scene->num_media > PMC_MAX_MEDIA) return fail(PMC_ERR_UNSUPPORTED, "more than PMC_MAX_MEDIA medium components");
+    if (scene->num_media > 1 && !scene->media) return fail(PMC_ERR_INVALID, "num_media > 1 without pmc_scene::media");
     if (scene->num_instruments < 1 || scene->num_instruments > PMC_MAX_INSTRUMENTS)
         return fail(PMC_ERR_UNSUPPORTED, "between 1 and " + std::to_string(PMC_MAX_INSTRUMENTS) + " instruments are supported");
     if (scene->grid.kind != PMC_GRID_CARTESIAN && scene->grid.kind != PMC_GRID_OCTREE && scene->grid.kind != PMC_GRID_VORONOI)

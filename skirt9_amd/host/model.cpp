@@ -780,7 +780,7 @@ namespace skh
         bool hasDustDensityDispersion = maxDustDensityDispersion > 0;
         double dustMass = hasDustFraction ? medium.totalMass() : 0.;
         double dustKappa = 0.;
-        if (hasDustOpticalDepth) dustKappa = medium.mix->sectionExt(policyWavelength) / medium.mix->mass();
+        if (hasDustOpticalDepth) dustKappa = medium.dustKappa(policyWavelength);
 
         nodes.clear();
         Node root;

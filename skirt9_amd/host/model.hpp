@@ -310,6 +310,58 @@ namespace skh
         }
         // wavelength that the medium's normalisation adds to the simulation wavelengths (0: none)
         virtual double normalizationWavelength() const { return 0.; }
+        // DensityTreePolicy::_dustKappa (DensityTreePolicy.cpp:74-84): extinction cross section over mass per dust entity
+        virtual double dustKappa(double lambda) const { return mix->sectionExt(lambda) / mix->mass(); }
+    };
+
+    // Several medium components seen as ONE dust distribution by the setup of the spatial grid: DensityTreePolicy sums the mass
+    // densities of all dust media at a sample position (DensityTreePolicy.cpp:141), their masses (:72) and, for the optical depth
+    // criterion, their cross sections and entity masses (:78-83).  The photon loop never sees this object: every component keeps
+    // its own cell densities and material mix (MediumSystem.cpp:874-887).
+    class CompositeMedium : public Medium
+    {
+    public:
+        std::vector<Medium*> parts;
+        std::string type() const override { return "media"; }
+        void setup() override {}
+        double numberDensity(Vec3) const override { throw std::runtime_error("number density of a composite medium"); }
+        double massDensity(Vec3 r) const override
+        {
+            double rho = 0.;
+            for (const Medium* part : parts) rho += part->massDensity(r);
+            return rho;
+        }
+        double totalMass() const override
+        {
+            double sum = 0.;
+            for (const Medium* part : parts) sum += part->totalMass();
+            return sum;
+        }
+        double totalNumber() const override { return 0.; }
+        Vec3 generatePosition(Random&) const override
+        {
+            throw std::runtime_error("unsupported: Voronoi sites drawn from the density of several medium components");
+        }
+        void massDensities(const std::vector<Vec3>& positions, std::vector<double>& out) const override
+        {
+            out.assign(positions.size(), 0.);
+            std::vector<double> one;
+            for (const Medium* part : parts)
+            {
+                part->massDensities(positions, one);
+                for (size_t i = 0; i != out.size(); ++i) out[i] += one[i];
+            }
+        }
+        double dustKappa(double lambda) const override
+        {
+            double sigma = 0., mu = 0.;
+            for (const Medium* part : parts)
+            {
+                sigma += part->mix->sectionExt(lambda);
+                mu += part->mix->mass();
+            }
+            return sigma / mu;
+        }
     };
 
     // GeometricMedium with OpticalDepth/Mass/Number material normalisation

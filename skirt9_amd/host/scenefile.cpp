@@ -87,13 +87,15 @@ namespace
         const size_t blocks = voro ? size_t(g.vblock_n) * g.vblock_n * g.vblock_n : 0;
         f(g.vblock_start, voro ? blocks + 1 : 0);
         f(g.vblock_list, voro ? size_t(g.vblock_start[blocks]) : 0);
-        pmc_medium& m = s.medium;
-        f(m.number_density, size_t(g.num_cells));
-        f(m.lambda_border, size_t(m.num_lambda));
-        f(m.sigma_ext, size_t(m.num_lambda));
-        f(m.sigma_sca, size_t(m.num_lambda));
-        f(m.asymmpar, size_t(m.num_lambda));
-        f(m.sigma_abs, size_t(m.num_lambda));
+        auto visitMedium = [&](pmc_medium& m) {
+            f(m.number_density, size_t(g.num_cells));
+            f(m.lambda_border, size_t(m.num_lambda));
+            f(m.sigma_ext, size_t(m.num_lambda));
+            f(m.sigma_sca, size_t(m.num_lambda));
+            f(m.asymmpar, size_t(m.num_lambda));
+            f(m.sigma_abs, size_t(m.num_lambda));
+        };
+        visitMedium(s.medium);
         visitSource(s.source, f);
         f(s.instruments, size_t(s.num_instruments));
         for (int i = 0; i < s.num_instruments; ++i)
@@ -109,6 +111,9 @@ namespace
         f(s.sources, ns);
         for (size_t i = 0; i < ns; ++i) visitSource(const_cast<pmc_source&>(s.sources[i]), f);
         f(s.source_first, ns ? ns + 1 : 0);
+        const size_t nm = s.num_media > 1 ? size_t(s.num_media) : 0;
+        f(s.media, nm);
+        for (size_t i = 0; i < nm; ++i) visitMedium(const_cast<pmc_medium&>(s.media[i]));
     }
 
     // save: the data of a member goes to the end of the blob, and the COPY of the structure that holds the member (it lives in
@@ -168,7 +173,7 @@ int skh_scene_save(const skh_simulation* h, const char* path)
             const size_t at = (member && bytes) ? S.append(member, bytes) : 0;
             fix.emplace_back(place(&member), (member && bytes) ? at : 0);
             // nested structures: their own pointer members are visited next, through the live array
-            if ((std::is_same<T, pmc_instrument>::value || std::is_same<T, pmc_source>::value) && member && bytes)
+            if ((std::is_same<T, pmc_instrument>::value || std::is_same<T, pmc_source>::value || std::is_same<T, pmc_medium>::value) && member && bytes)
                 regions.push_back({reinterpret_cast<const char*>(member), bytes, at});
         });
         for (const auto& f : fix)

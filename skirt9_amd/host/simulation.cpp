@@ -395,8 +395,14 @@ namespace skh
             }
         if (const XmlElement* so = ms->item("samplingOptions")) _numDensitySamples = rd.integer(*so, "numDensitySamples", 100);
         auto media = ms->items("media");
-        if (media.size() != 1) unsupported("a medium system with " + std::to_string(media.size()) + " media");
-        const XmlElement& med = *media[0];
+        if (media.empty()) unsupported("a medium system without media");
+        if (media.size() > PMC_MAX_MEDIA) unsupported("a medium system with more than " + std::to_string(PMC_MAX_MEDIA) + " media");
+        // (several components: every one a dust medium with spatially constant cross sections --
+        // Configuration::hasMultipleConstantSectionMedia, MediumSystem.cpp:874-887)
+        for (const XmlElement* mediumElement : media)
+        {
+        const XmlElement& med = *mediumElement;
+        std::unique_ptr<Medium> one;
         if (med.name != "GeometricMedium" && med.name != "ParticleMedium") unsupported("medium " + med.name);
         if (med.item("velocityDistribution") && rd.quantity(med, "velocityMagnitude", "velocity", "0") && !_oligo)
             unsupported("a medium with a velocity field");
@@ -455,7 +461,7 @@ namespace skh
                 gm->normNumber = rd.number(*mn, "number");
             else
                 unsupported("material normalization " + mn->name);
-            _medium = std::move(gm);
+            one = std::move(gm);
         }
         else
         {
@@ -476,9 +482,13 @@ namespace skh
             if (rd.boolean(med, "importVariableMixParams", false)) unsupported("an imported medium with a variable material mix");
             if (!med.attr("useColumns", "").empty()) unsupported("useColumns (column remapping)");
             if (const XmlElement* sk = med.item("smoothingKernel")) pm->kernelType = sk->name;
-            _medium = std::move(pm);
+            one = std::move(pm);
         }
-        _medium->mix = std::move(mix);
+        one->mix = std::move(mix);
+        _media.push_back(std::move(one));
+        }  // media
+        for (auto& part : _media) _composite.parts.push_back(part.get());
+        _medium = _media.size() == 1 ? _media[0].get() : &_composite;
 
         const XmlElement* ge = ms->item("grid");
         if (!ge) throw std::runtime_error("ski: MediumSystem lacks a spatial grid");
@@ -686,11 +696,12 @@ namespace skh
         for (auto& ins : _instruments)
             if (ins.ownGrid) addGrid(ins.ownGrid.get());
         // MaterialWavelengthRangeInterface items: the normalisation wavelength and the tree policy wavelength
-        if (_medium->normalizationWavelength() > 0)
-        {
-            extend(_medium->normalizationWavelength(), _medium->normalizationWavelength());
-            simWavelengths.insert(_medium->normalizationWavelength());
-        }
+        for (auto& part : _media)
+            if (part->normalizationWavelength() > 0)
+            {
+                extend(part->normalizationWavelength(), part->normalizationWavelength());
+                simWavelengths.insert(part->normalizationWavelength());
+            }
         if (auto tree = dynamic_cast<OctreeSpatialGrid*>(_grid.get()))
             if (tree->maxDustOpticalDepth > 0 && tree->policyWavelength > 0)
             {
@@ -701,9 +712,12 @@ namespace skh
         rangeMax *= (1. + 1. / 100.);
 
         // ---- dust mix, medium normalisation
-        _medium->mix->setup(rangeMin, rangeMax, std::vector<double>(simWavelengths.begin(), simWavelengths.end()));
-        if (auto pm = dynamic_cast<ParticleMedium*>(_medium.get())) pm->snapshot.useDeviceSampler(_samplerApi);
-        _medium->setup();
+        for (auto& part : _media)
+        {
+            part->mix->setup(rangeMin, rangeMax, std::vector<double>(simWavelengths.begin(), simWavelengths.end()));
+            if (auto pm = dynamic_cast<ParticleMedium*>(part.get())) pm->snapshot.useDeviceSampler(_samplerApi);
+            part->setup();
+        }
 
         // ---- spatial grid (tree construction draws from the random stream) then cell densities
         if (auto cart = dynamic_cast<CartesianSpatialGrid*>(_grid.get()))
@@ -719,11 +733,14 @@ namespace skh
             voro->setup(_random, *_medium);
 
         // MediumSystem::setupSelfAfter density sampling (MediumSystem.cpp:80-106,308-321)
+        // (the sample positions of a cell are drawn once and serve every component: PropertySampler::prepareForCell, :80-96)
         int numCells = _grid->numCells();
-        _density.assign(numCells, 0.);
+        const size_t H = _media.size();
+        _density.assign(H, Array(numCells, 0.));
         if (_numDensitySamples == 1)
         {
-            for (int m = 0; m != numCells; ++m) _density[m] = _medium->numberDensity(_grid->centralPositionInCell(m));
+            for (size_t h = 0; h != H; ++h)
+                for (int m = 0; m != numCells; ++m) _density[h][m] = _media[h]->numberDensity(_grid->centralPositionInCell(m));
         }
         else
         {
@@ -739,13 +756,16 @@ namespace skh
                 {
                     for (int n = 0; n != _numDensitySamples; ++n) pos.push_back(_grid->randomPositionInCell(m, _random));
                 }
-                _medium->numberDensities(pos, samples);
-                size_t at = 0;
-                for (int m = m0; m != m1; ++m)
+                for (size_t h = 0; h != H; ++h)
                 {
-                    double sum = 0.;
-                    for (int n = 0; n != _numDensitySamples; ++n) sum += samples[at++];
-                    _density[m] = sum / _numDensitySamples;
+                    _media[h]->numberDensities(pos, samples);
+                    size_t at = 0;
+                    for (int m = m0; m != m1; ++m)
+                    {
+                        double sum = 0.;
+                        for (int n = 0; n != _numDensitySamples; ++n) sum += samples[at++];
+                        _density[h][m] = sum / _numDensitySamples;
+                    }
                 }
             }
         }
@@ -989,14 +1009,22 @@ namespace skh
         g.num_cells = _grid->numCells();
         _grid->fill(g);
 
-        pmc_medium& m = _scene.medium;
-        m.number_density = _density.data();
-        m.num_lambda = static_cast<int32_t>(_medium->mix->lambdaBorder.size());
-        m.lambda_border = _medium->mix->lambdaBorder.data();
-        m.sigma_ext = _medium->mix->sigmaExt.data();
-        m.sigma_sca = _medium->mix->sigmaSca.data();
-        m.sigma_abs = _medium->mix->sigmaAbs.data();
-        m.asymmpar = _medium->mix->asymmpar.data();
+        _sceneMedia.assign(_media.size(), pmc_medium());
+        for (size_t h = 0; h != _media.size(); ++h)
+        {
+            pmc_medium& m = _sceneMedia[h];
+            const DustMix& mix = *_media[h]->mix;
+            m.number_density = _density[h].data();
+            m.num_lambda = static_cast<int32_t>(mix.lambdaBorder.size());
+            m.lambda_border = mix.lambdaBorder.data();
+            m.sigma_ext = mix.sigmaExt.data();
+            m.sigma_sca = mix.sigmaSca.data();
+            m.sigma_abs = mix.sigmaAbs.data();
+            m.asymmpar = mix.asymmpar.data();
+        }
+        _scene.medium = _sceneMedia[0];
+        _scene.num_media = static_cast<int32_t>(_media.size());
+        _scene.media = _media.size() > 1 ? _sceneMedia.data() : nullptr;
 
         _scene.options = _options;
 

@@ -54,7 +54,7 @@ namespace skh
         // model objects, exposed for tests
         const SpatialGrid& grid() const { return *_grid; }
         const Medium& medium() const { return *_medium; }
-        const Array& numberDensity() const { return _density; }
+        const Array& numberDensity(size_t h = 0) const { return _density[h]; }
         const SourceModel& source(int h = 0) const { return _sources[h]; }
         int numSources() const { return static_cast<int>(_sources.size()); }
 
@@ -88,10 +88,13 @@ namespace skh
         // medium system
         pmc_options _options{};
         int _numDensitySamples{100};
-        std::unique_ptr<Medium> _medium;
+        std::vector<std::unique_ptr<Medium>> _media;   // the medium components, in ski order (MediumSystem::_media)
+        CompositeMedium _composite;                    // all of them as one dust distribution (grid setup)
+        Medium* _medium{nullptr};                      // the only component, or the composite
         std::unique_ptr<SpatialGrid> _grid;
         std::vector<char> _topology;
-        Array _density;
+        std::vector<Array> _density;                   // [component][cell] number densities
+        std::vector<pmc_medium> _sceneMedia;
         // radiation field
         bool _storeRadiationField{false};
         std::unique_ptr<WavelengthGrid> _rfGridOwn;       // radiationFieldWLG as configured (panchromatic)
