@@ -477,6 +477,7 @@ namespace
         for (double** d : dbl)
             if ((rc = ctx->allocate<double>(n, d, false, &own))) return rc;
         if (ctx->dev.explicit_absorption && (rc = ctx->allocate<double>(n, &A.dustAbs, false, &own))) return rc;
+        if (ctx->dev.num_media > 1 && !ctx->dev.mono && (rc = ctx->allocate<int32_t>(n * ctx->dev.num_media, &A.dustIdx, false, &own))) return rc;
         if ((rc = ctx->allocate<uint64_t>(n, &A.history, false, &own))) return rc;
         if ((rc = ctx->allocate<uint32_t>(n, &A.rngBlock, false, &own))) return rc;
         int32_t** ints[] = {&A.mode, &A.nscatt, &A.mint};
@@ -657,6 +658,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
 
     DevScene& D = ctx->dev;
     const pmc_grid& g = scene->grid;
+    std::vector<int32_t> devToCell;  // octree: device cell index -> caller's cell index (else empty: the same numbering)
     D.grid_kind = g.kind;
     D.gx0 = g.xmin, D.gy0 = g.ymin, D.gz0 = g.zmin;
     D.gx1 = g.xmax, D.gy1 = g.ymax, D.gz1 = g.zmax;
@@ -820,6 +822,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if ((rc = ctx->upload(T.nbrStart.data(), T.nbrStart.size(), &D.nbr_start))) return bail(rc);
         if ((rc = ctx->upload(T.nbrList.data(), T.nbrList.size(), &D.nbr_list))) return bail(rc);
         if ((rc = ctx->upload(T.cellExt.data(), T.cellExt.size(), &D.cell_ext))) return bail(rc);
+        devToCell = T.cellExt;
         D.cell_slots = T.cellSlots;
         // (levels 13-15: 0.2-0.8 MB: not in LDS; the walk reads the six walls of a step from global memory)
         D.tab_in_lds = T.lmax <= 12 ? 1 : 0;
@@ -827,7 +830,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     }
 
     // ---- medium
-    const pmc_medium& med = scene->medium;
+    const pmc_medium& med = scene->num_media > 1 ? scene->media[0] : scene->medium;
     D.num_lambda = med.num_lambda;
     if ((rc = ctx->upload(med.lambda_border, med.num_lambda, &D.lambda_border))) return bail(rc);
     if ((rc = ctx->upload(med.sigma_ext, med.num_lambda, &D.sigma_ext))) return bail(rc);
@@ -839,6 +842,33 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     {
         if (!med.sigma_abs) return bail(fail(PMC_ERR_INVALID, "explicit absorption needs pmc_medium::sigma_abs"));
         if ((rc = ctx->upload(med.sigma_abs, med.num_lambda, &D.sigma_abs))) return bail(rc);
+    }
+    // several components: every one's densities (in the device numbering of the cells) and dust tables
+    D.num_media = scene->num_media > 1 ? scene->num_media : 1;
+    std::memset(D.med, 0, sizeof(D.med));
+    if (D.num_media > 1)
+    {
+        const size_t slots = devToCell.empty() ? size_t(g.num_cells) : devToCell.size();
+        std::vector<double> dens(slots);
+        for (int h = 0; h < D.num_media; ++h)
+        {
+            const pmc_medium& mh = scene->media[h];
+            if (!mh.number_density || !mh.lambda_border || !mh.sigma_ext || !mh.sigma_sca || !mh.asymmpar || !mh.sigma_abs || mh.num_lambda < 1)
+                return bail(fail(PMC_ERR_INVALID, "incomplete medium component"));
+            for (size_t dev = 0; dev < slots; ++dev)
+            {
+                const int64_t m = devToCell.empty() ? int64_t(dev) : int64_t(devToCell[dev]);
+                dens[dev] = m >= 0 ? mh.number_density[m] : 0.;
+            }
+            DevMedium& M = D.med[h];
+            M.num_lambda = mh.num_lambda;
+            if ((rc = ctx->upload(dens.data(), dens.size(), &M.density))) return bail(rc);
+            if ((rc = ctx->upload(mh.lambda_border, mh.num_lambda, &M.lambda_border))) return bail(rc);
+            if ((rc = ctx->upload(mh.sigma_ext, mh.num_lambda, &M.sigma_ext))) return bail(rc);
+            if ((rc = ctx->upload(mh.sigma_sca, mh.num_lambda, &M.sigma_sca))) return bail(rc);
+            if ((rc = ctx->upload(mh.sigma_abs, mh.num_lambda, &M.sigma_abs))) return bail(rc);
+            if ((rc = ctx->upload(mh.asymmpar, mh.num_lambda, &M.asymmpar))) return bail(rc);
+        }
     }
     int walkDoubles = D.lds_grid_len;   // walk kernels and cycle start kernel: the grid tables, at offset 0
     int transDoubles = 0;               // transition and launch kernels: no grid tables
@@ -932,6 +962,26 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         D.mono_lambda = lambda;
         D.mono_ext = med.sigma_ext[il], D.mono_sca = med.sigma_sca[il], D.mono_asym = med.asymmpar[il];
         if (D.explicit_absorption) D.mono_abs = med.sigma_abs[il];
+        for (int h = 0; h < D.num_media && D.num_media > 1; ++h)
+        {
+            const pmc_medium& mh = scene->media[h];
+            int ih = 0;
+            if (!(lambda < mh.lambda_border[0]))
+            {
+                int jl = -1, ju = mh.num_lambda - 1;
+                while (ju - jl > 1)
+                {
+                    const int jm = (ju + jl) >> 1;
+                    if (lambda < mh.lambda_border[jm])
+                        ju = jm;
+                    else
+                        jl = jm;
+                }
+                ih = jl;
+            }
+            D.med[h].mono_ext = mh.sigma_ext[ih], D.med[h].mono_sca = mh.sigma_sca[ih], D.med[h].mono_abs = mh.sigma_abs[ih];
+            D.med[h].mono_asym = mh.asymmpar[ih];
+        }
     }
 
     // ---- instruments and frame layout
@@ -1323,16 +1373,16 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 HIP_TRY(hipStreamWaitEvent(sp, ctx->evA[g], 0));
                 for (int i = 0; i < D.num_instruments; ++i)
                     if (!D.inst[i].same_observer)
-                        HIP_TRY(pmcLaunchPeel(ctx->slot, ctx->wide, base[g], numTasks, list, PMC_CTR_TASK(g, 1 + i), i, peelGrid, ctx->walkLds, sp));
+                        HIP_TRY(pmcLaunchPeel(ctx->slot, (ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), base[g], numTasks, list, PMC_CTR_TASK(g, 1 + i), i, peelGrid, ctx->walkLds, sp));
                 HIP_TRY(hipEventRecord(ctx->evJoin[g], sp));
                 RfLogArgs log = {ctx->rfKeys[g][0], ctx->rfVals[g][0], rfLogged ? ctx->rfCap[g] : 0ull, PMC_CTR_RFLOG(g), rfPadKey};
                 if (serialWalks) HIP_TRY(hipEventRecord(ctx->evProp[g], sg));  // (in series: the propagation kernel starts where the peel-off kernels end)
-                HIP_TRY(pmcLaunchProp(ctx->slot, ctx->wide, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0), base[g], numTasks, list, PMC_CTR_TASK(g, 0), seed, propGrid, ctx->walkLds, &log, sg));
+                HIP_TRY(pmcLaunchProp(ctx->slot, ctx->wide, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0) | (D.num_media > 1 ? 4 : 0), base[g], numTasks, list, PMC_CTR_TASK(g, 0), seed, propGrid, ctx->walkLds, &log, sg));
                 if (!serialWalks) HIP_TRY(hipEventRecord(ctx->evProp[g], sg));
                 HIP_TRY(hipStreamWaitEvent(sg, ctx->evJoin[g], 0));
             }
             else
-                HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0), base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->block,
+                HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0) | (D.num_media > 1 ? 4 : 0), base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->block,
                                       ctx->walkLds, sg));
             haveWalk[g] = true;
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));

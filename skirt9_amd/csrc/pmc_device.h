@@ -115,6 +115,8 @@ struct SlotArrays
     uint32_t* rngBlock;                     // (block << 1) | have
     double* dustExt; double* dustSca;       // extinction and scattering cross section of the dust mix at the history's wavelength
     double* dustAbs;                        // (explicit-absorption cycle only, else null) its absorption cross section
+    int32_t* dustIdx;                       // (several medium components, panchromatic: else null) [num_media][num_slots] index of the
+                                            // history's wavelength in every component's dust tables
     double* dustAsym;                       // and its asymmetry parameter: DustMix::indexForLambda(lambda) is looked up ONCE, at launch
     int32_t* mode;                          // bit 5 alive, bits 8-23 observers (group leaders) with a peel-off packet this cycle
     int32_t* nscatt;
@@ -199,6 +201,20 @@ struct DevSource
     double  sed_f1, sed_f2, sed_ltot;
 };
 
+// one medium component of a system of several (pmc.h pmc_scene::media): its cell densities in the DEVICE numbering of the cells and its
+// dust tables; mono_*: its properties at the one wavelength of an oligochromatic scene (DevScene::mono)
+struct DevMedium
+{
+    const double* density;
+    const double* lambda_border;
+    const double* sigma_ext;
+    const double* sigma_sca;
+    const double* sigma_abs;
+    const double* asymmpar;
+    int32_t num_lambda;
+    double mono_ext, mono_sca, mono_abs, mono_asym;
+};
+
 struct DevScene
 {
     // ---- grid
@@ -260,6 +276,10 @@ struct DevScene
     // ---- options
     int32_t force_scattering;
     int32_t explicit_absorption;  // PhotonPacketOptions::explicitAbsorption (pmc.h pmc_options)
+    // ---- several medium components (num_media > 1; else the members above describe the only one): MediumSystem.cpp:874-887, 678-730,
+    // 796-817.  Component 0 is ALSO what the members above describe (the hot cell records carry its density).
+    int32_t num_media;
+    DevMedium med[PMC_MAX_MEDIA];
     double  min_weight_reduction;
     int32_t min_scatt_events;
     double  path_length_bias;

@@ -264,36 +264,54 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
     {
         const void* kernel;
         size_t lds;
-    } all[] = {{reinterpret_cast<const void*>(&walkPeelKernel<false>), walkMax},
-               {reinterpret_cast<const void*>(&walkPeelKernel<true>), walkMax},
+    } all[] = {{reinterpret_cast<const void*>(&walkPeelKernel<false, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkPeelKernel<true, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkPeelKernel<false, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPeelKernel<true, true>), walkMax},
                {reinterpret_cast<const void*>(&walkPeelKernel2<false>), std::min(walkMax + 16 + pmcPeelQueueBytes(), size_t(160) * 1024)},
                {reinterpret_cast<const void*>(&walkPeelKernel2<true>), std::min(walkMax + 16 + pmcPeelQueueBytes(), size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPropKernel<false, false, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPropKernel<false, true, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPropKernel<true, false, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPropKernel<true, true, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPropKernel<false, false, true>), walkMax},
-               {reinterpret_cast<const void*>(&walkPropKernel<false, true, true>), walkMax},
-               {reinterpret_cast<const void*>(&walkPropKernel<true, false, true>), walkMax},
-               {reinterpret_cast<const void*>(&walkPropKernel<true, true, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, false, false, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, true, false, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, false, false, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, true, false, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, false, true, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, true, true, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, false, true, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, true, true, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, false, false, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, false, true, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, true, false, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, true, true, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, false, false, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, false, true, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, true, false, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, true, true, true>), walkMax},
                {reinterpret_cast<const void*>(&traceTreeKernel<false, false>), walkMax},
                {reinterpret_cast<const void*>(&traceTreeKernel<false, true>), walkMax},
                {reinterpret_cast<const void*>(&traceTreeKernel<true, false>), walkMax},
                {reinterpret_cast<const void*>(&traceTreeKernel<true, true>), walkMax},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, false, false>), walkMax},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, true, false>), walkMax},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, false, true>), walkMax},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, true, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, false, false, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, true, false, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, false, true, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, true, true, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, false, false, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, false, true, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, true, false, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_CART, true, true, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, false, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, true, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, true, false, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, true, true, true>), walkMax},
                {reinterpret_cast<const void*>(&traceRayKernel<GRID_CART>), walkMax},
                {reinterpret_cast<const void*>(&transitionKernel), transitionMax},
                {reinterpret_cast<const void*>(&launchKernel), transitionMax},
                {reinterpret_cast<const void*>(&cycleStartKernel<GRID_TREE>), walkMax},
                {reinterpret_cast<const void*>(&cycleStartKernel<GRID_CART>), walkMax},
                {reinterpret_cast<const void*>(&cycleStartKernel<GRID_VORO>), walkMax},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, false>), walkMax},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, true, false>), walkMax},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, true>), walkMax},
-               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, true, true>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, false, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, true, false, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, true, false>), walkMax},
+               {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, true, true, false>), walkMax},
                {reinterpret_cast<const void*>(&traceRayKernel<GRID_VORO>), walkMax}};
     for (const auto& k : all)
     {
@@ -310,20 +328,20 @@ extern "C" int pmcWalkBlocksPerCU(int gridKind, int kind, int wide, int block, s
     int n = 0;
     hipError_t e;
     if (gridKind == PMC_GRID_OCTREE && kind == 1)
-        e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPeelKernel<true>), block, ldsBytes)
-                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPeelKernel<false>), block, ldsBytes);
+        e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPeelKernel<true, false>), block, ldsBytes)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPeelKernel<false, false>), block, ldsBytes);
     else if (gridKind == PMC_GRID_OCTREE)
     {
         // (with the pass-1 records of pmcLaunchProp)
         const size_t trimOffset = (ldsBytes + 15) & ~size_t(15);
         if (!getenv("PMC_PROP_NO_TRIM") && trimOffset + PROP_TRIM_BYTES <= size_t(160) * 1024) ldsBytes = trimOffset + PROP_TRIM_BYTES;
-        e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<true, false, false>), block, ldsBytes)
-                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<false, false, false>), block, ldsBytes);
+        e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<true, false, false, false>), block, ldsBytes)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<false, false, false, false>), block, ldsBytes);
     }
     else if (gridKind == PMC_GRID_VORONOI)
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, false>), block, ldsBytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, false, false>), block, ldsBytes);
     else
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_CART, false, false>), block, ldsBytes);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkKernel<GRID_CART, false, false, false>), block, ldsBytes);
     return e == hipSuccess ? n : 0;
 }
 
@@ -344,10 +362,16 @@ extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int tas
 {
     // (the radiation-field and the explicit-absorption flavours are separate instantiations: the plain photon loop pays nothing for
     // them; storeRf: bit 0 = the radiation field is stored, bit 1 = explicit absorption)
-    const bool rf = (storeRf & 1) != 0, ea = (storeRf & 2) != 0;
-    auto kernel = gridKind == PMC_GRID_VORONOI
-                      ? (ea ? (rf ? walkKernel<GRID_VORO, true, true> : walkKernel<GRID_VORO, false, true>) : (rf ? walkKernel<GRID_VORO, true, false> : walkKernel<GRID_VORO, false, false>))
-                      : (ea ? (rf ? walkKernel<GRID_CART, true, true> : walkKernel<GRID_CART, false, true>) : (rf ? walkKernel<GRID_CART, true, false> : walkKernel<GRID_CART, false, false>));
+    // (bit 2 = several medium components)
+    const int flavour = storeRf & 7;
+    typedef void (*Kernel)(int, int, int, int, uint64_t);
+    static const Kernel cart[8] = {walkKernel<GRID_CART, false, false, false>, walkKernel<GRID_CART, true, false, false>, walkKernel<GRID_CART, false, true, false>,
+                                   walkKernel<GRID_CART, true, true, false>,   walkKernel<GRID_CART, false, false, true>, walkKernel<GRID_CART, true, false, true>,
+                                   walkKernel<GRID_CART, false, true, true>,   walkKernel<GRID_CART, true, true, true>};
+    static const Kernel voro[8] = {walkKernel<GRID_VORO, false, false, false>, walkKernel<GRID_VORO, true, false, false>, walkKernel<GRID_VORO, false, true, false>,
+                                   walkKernel<GRID_VORO, true, true, false>,   walkKernel<GRID_VORO, false, false, true>, walkKernel<GRID_VORO, true, false, true>,
+                                   walkKernel<GRID_VORO, false, true, true>,   walkKernel<GRID_VORO, true, true, true>};
+    const Kernel kernel = gridKind == PMC_GRID_VORONOI ? voro[flavour] : cart[flavour];
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter, seed);
     return hipGetLastError();
 }
@@ -357,10 +381,13 @@ extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlo
                                     hipStream_t stream)
 {
     static const bool first = getenv("PMC_PEEL_V1") != nullptr;  // (tuning aid: the form with service rounds)
+    // (`wide` bit 1: several medium components -- the form with service rounds)
+    const bool mm = (wide & 2) != 0;
+    wide &= 1;
     // (an octree of 12 levels leaves no room for the task queues next to its coordinate table: service rounds)
-    if (first || ((ldsBytes + 15) & ~size_t(15)) + pmcPeelQueueBytes() > size_t(160) * 1024)
+    if (first || mm || ((ldsBytes + 15) & ~size_t(15)) + pmcPeelQueueBytes() > size_t(160) * 1024)
     {
-        auto kernel = wide ? walkPeelKernel<true> : walkPeelKernel<false>;
+        auto kernel = mm ? (wide ? walkPeelKernel<true, true> : walkPeelKernel<false, true>) : (wide ? walkPeelKernel<true, false> : walkPeelKernel<false, false>);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PEEL_BLOCK), ldsBytes, stream, slot, slotBase, numSlots, cursor, obs, list);
     }
     else
@@ -379,13 +406,20 @@ extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBas
                                     size_t ldsBytes, const RfLogArgs* rfLog, hipStream_t stream)
 {
     // (storeRf: bit 0 = the radiation field is stored, bit 1 = explicit absorption)
-    const bool rf = (storeRf & 1) != 0, ea = (storeRf & 2) != 0;
-    auto kernel = wide ? (ea ? (rf ? walkPropKernel<true, true, true> : walkPropKernel<true, false, true>) : (rf ? walkPropKernel<true, true, false> : walkPropKernel<true, false, false>))
-                       : (ea ? (rf ? walkPropKernel<false, true, true> : walkPropKernel<false, false, true>) : (rf ? walkPropKernel<false, true, false> : walkPropKernel<false, false, false>));
+    // (bit 2 = several medium components)
+    const bool ea = (storeRf & 2) != 0, mm = (storeRf & 4) != 0;
+    typedef void (*Kernel)(int, int, int, int, uint64_t, int, RfLogArgs, const int*);
+    static const Kernel narrow[8] = {walkPropKernel<false, false, false, false>, walkPropKernel<false, true, false, false>, walkPropKernel<false, false, true, false>,
+                                     walkPropKernel<false, true, true, false>,   walkPropKernel<false, false, false, true>, walkPropKernel<false, true, false, true>,
+                                     walkPropKernel<false, false, true, true>,   walkPropKernel<false, true, true, true>};
+    static const Kernel wider[8] = {walkPropKernel<true, false, false, false>, walkPropKernel<true, true, false, false>, walkPropKernel<true, false, true, false>,
+                                    walkPropKernel<true, true, true, false>,   walkPropKernel<true, false, false, true>, walkPropKernel<true, true, false, true>,
+                                    walkPropKernel<true, false, true, true>,   walkPropKernel<true, true, true, true>};
+    const Kernel kernel = wide ? wider[storeRf & 7] : narrow[storeRf & 7];
     // (the pass-1 records follow the grid tables in LDS, if there is room)
     static const bool noTrim = getenv("PMC_PROP_NO_TRIM") != nullptr;  // (tuning aid)
     const size_t trimOffset = (ldsBytes + 15) & ~size_t(15);
-    const bool trim = !noTrim && !ea && trimOffset + PROP_TRIM_BYTES <= size_t(160) * 1024;
+    const bool trim = !noTrim && !ea && !mm && trimOffset + PROP_TRIM_BYTES <= size_t(160) * 1024;
     RfLogArgs none = {nullptr, nullptr, 0ull, 0, 0u};
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PROP_BLOCK), trim ? trimOffset + PROP_TRIM_BYTES : ldsBytes, stream, slot, slotBase, numSlots, cursor,
                        seed, trim ? (int)trimOffset : -1, rfLog ? *rfLog : none, list);

@@ -83,7 +83,7 @@ def _compare_frames(sim, gpu, ref, n):
             assert a[:lay.num_lambda].sum() == n
 
 
-@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg2nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg3file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg3ten.ski", 20000), ("cfg3twelve.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg1long.ski", 5000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000), ("cfg2deep.ski", 20000), ("cfg2deeper.ski", 20000), ("cfg2ea.ski", 20000), ("cfg1nfea.ski", 50000)])
+@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg2nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg3file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg3ten.ski", 20000), ("cfg3twelve.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg1long.ski", 5000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000), ("cfg2deep.ski", 20000), ("cfg2deeper.ski", 20000), ("cfg2ea.ski", 20000), ("cfg1nfea.ski", 50000), ("cfg2mm.ski", 20000), ("cfg2mmea.ski", 20000), ("cfg1mmnf.ski", 50000), ("cfg3mm.ski", 20000)])
 def test_photon_loop_matches_oracle(name, n):
     sim = Simulation(ski(name), num_packets=n).setup()
     eng = _engine(sim)
@@ -127,6 +127,51 @@ def test_explicit_absorption_matches_oracle(name, n, tmp_path):
     assert abs(c["cell_visits"] - counters.cell_visits) <= 1e-4 * counters.cell_visits
     assert abs(c["scatterings"] - counters.scatterings) <= 1e-4 * counters.scatterings + 2
     _compare_frames(sim, gpu, ref, n)
+
+
+SECOND_COMPONENT = """</GeometricMedium><GeometricMedium velocityMagnitude="0 km/s" magneticFieldStrength="0 uG">
+     <geometry type="Geometry"><PlummerGeometry scaleLength="1500 pc"/></geometry>
+     <materialMix type="MaterialMix"><MeanListDustMix wavelengths="0.1 micron, 1 micron" extinctionCoefficients="5000 m2/kg, 1200 m2/kg" albedos="0.8, 0.4" asymmetryParameters="0.1, 0.9"/></materialMix>
+     <normalization type="MaterialNormalization"><MassMaterialNormalization mass="2e6 Msun"/></normalization>
+    </GeometricMedium>"""
+
+
+@pytest.mark.parametrize("name,n,ea", [("cfg5small.ski", 20000, False), ("cfg2deep.ski", 20000, False), ("cfg3ten.ski", 20000, True), ("cfg2nf.ski", 50000, True),
+                                       ("cfg2nf.ski", 50000, False), ("cfg3rfea.ski", 20000, True), ("cfg5small.ski", 20000, True)])
+def test_several_components_match_oracle(name, n, ea, tmp_path):
+    """hasMultipleConstantSectionMedia branches (MediumSystem.cpp:874-887, 934-955, 1013-1037, 1112-1153, 1225-1242; albedo and weights
+    :678-730; component pick :806-817; consolidated peel-off :734-767): a second component (Plummer sphere, another dust mix) added to
+    scenes of the parity list -- Voronoi, the 21-bit octree kernels, ten sources (panchromatic: a wavelength bin per component in the
+    slot), the non-forced cycle with and without explicit absorption, radiation field -- HIP engine against the oracle, which the
+    reference's own files pin on cfg2mm / cfg2mmea / cfg1mmnf / cfg3mm / cfg1mmrf (test_oracle_golden.py)"""
+    import shutil
+    text = open(ski(name)).read()
+    assert text.count("</GeometricMedium>") == 1
+    text = text.replace("</GeometricMedium>", SECOND_COMPONENT)
+    if ea: text = text.replace('explicitAbsorption="false"', 'explicitAbsorption="true"')
+    for f in os.listdir(os.path.dirname(ski(name))):
+        if f.endswith(".txt"):
+            shutil.copy(ski(f), tmp_path / f)
+    path = tmp_path / name.replace(".ski", "mm.ski")
+    path.write_text(text)
+    sim = Simulation(str(path), num_packets=n).setup()
+    eng = _engine(sim)
+    eng.run_primary(0, n, 4242)
+    gpu = eng.download()
+    ref, counters = O.run_primary(sim, 0, n, O.RNG_PHILOX, seed=4242)
+    plain, _ = O.run_primary(Simulation(ski(name), num_packets=n).setup(), 0, n, O.RNG_PHILOX, seed=4242)
+    assert abs(plain.sum() - ref.sum()) > 1e-6 * np.abs(ref).sum()
+    c = eng.counters()
+    assert c["histories"] == n and c["stat_overflows"] == 0
+    assert abs(c["cell_visits"] - counters.cell_visits) <= 1e-4 * counters.cell_visits
+    assert abs(c["scatterings"] - counters.scatterings) <= 1e-4 * counters.scatterings + 2
+    _compare_frames(sim, gpu, ref, n)
+    if sim.radiation_field_size > 0:
+        gpu_rf = eng.download_radiation_field()
+        _, ref_rf, _ = O.run_primary_rf(sim, 0, n, O.RNG_PHILOX, seed=4242)
+        assert abs(gpu_rf.sum() - ref_rf.sum()) <= 1e-9 * ref_rf.sum()
+        assert np.array_equal(gpu_rf > 0, ref_rf > 0)
+        assert (np.abs(gpu_rf - ref_rf) > 1e-6 * np.abs(ref_rf) + 1e-13 * ref_rf.max()).sum() == 0
 
 
 def test_deep_octree_uses_the_wide_kernels():
@@ -194,7 +239,7 @@ def test_fits_output_from_gpu(tmp_path):
     assert abs(sed[2] - 2.943198361e-06) < 1e-9 * 2.94e-06 + 5 * 4e-3 * 2.94e-06
 
 
-@pytest.mark.parametrize("name,n", [("cfg1rf.ski", 20000), ("cfg3rf.ski", 20000), ("cfg1rfea.ski", 20000), ("cfg3rfea.ski", 20000)])
+@pytest.mark.parametrize("name,n", [("cfg1rf.ski", 20000), ("cfg3rf.ski", 20000), ("cfg1rfea.ski", 20000), ("cfg3rfea.ski", 20000), ("cfg1mmrf.ski", 20000)])
 def test_radiation_field_matches_oracle(name, n):
     """storeRadiationField on the GPU (walk kernel flavour RF: L * lnmean(e^-tau0, e^-tau1) * ds per path segment, f64
     atomics into rf[m * nbins + ell]) against the oracle following the same Philox histories: totals to 1e-9, cells
