@@ -12,7 +12,6 @@
 #include "pmc_device.h"
 #include "../../include/pmc_layout.h"
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -36,7 +35,10 @@ extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlo
                                     hipStream_t stream);
 extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, const int* list, int cursor, uint64_t seed, int grid,
                                     size_t ldsBytes, const RfLogArgs* rfLog, hipStream_t stream);
-extern "C" hipError_t pmcLaunchRfReduce(int slot, const uint32_t* keys, const double* vals, unsigned long long n, int numBuckets, hipStream_t stream);
+extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n,
+                                       int numParts, void* temp, int numCU, hipStream_t stream);
+extern "C" size_t pmcRfTempBytes(int numParts);
+extern "C" int pmcRfMaxParts();
 extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, const int* list, int listLen, int maxBlocks,
                                           size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchLaunch(int slot, int slotBase, int numSlots, int group, uint64_t first, uint64_t count, uint64_t seed, int initial,
@@ -1227,17 +1229,17 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     // which is partitioned by key range and summed after the generation.  128 entries per slot (config 2: 60 per propagation
     // walk on average); a wave that finds the log full falls back to atomic adds into the table.
     const int64_t rfSize = ctx->rfSize;
-    const bool rfLogged = D.rf_store && D.grid_kind == PMC_GRID_OCTREE && rfSize < (int64_t(1) << 31) && getenv("PMC_RF_ATOMICS") == nullptr;
-    const int rfBuckets = rfLogged ? int((rfSize + (int64_t(1) << PMC_RF_BUCKET_BITS) - 1) >> PMC_RF_BUCKET_BITS) : 0;
-    int rfSortBits = 0;
-    while (rfBuckets > 1 && (1 << rfSortBits) < rfBuckets + 1) ++rfSortBits;  // (+ 1: the partition of the entries that fill up chunks)
+    // (tables beyond 2^25 entries have more partitions than the counting sort's LDS histogram holds: atomics)
+    const int64_t rfParts = (rfSize + (int64_t(1) << PMC_RF_BUCKET_BITS) - 1) >> PMC_RF_BUCKET_BITS;
+    const bool rfLogged = D.rf_store && D.grid_kind == PMC_GRID_OCTREE && rfParts <= pmcRfMaxParts() && getenv("PMC_RF_ATOMICS") == nullptr;
+    const int rfBuckets = rfLogged ? int(rfParts) : 0;
     const uint32_t rfPadKey = uint32_t(rfBuckets) << PMC_RF_BUCKET_BITS;
     if (rfLogged)
         for (int g = 0; g < G; ++g)
         {
             unsigned long long perSlot = 128ull;
             if (const char* env = getenv("PMC_RF_LOG_PER_SLOT")) perSlot = std::max(1, atoi(env));  // (tests: a log that overflows)
-            // (the partition pass counts its entries in an int: at most 2^31 - 1 of them, in whole chunks; a wave that finds the log
+            // (positions in the partitioned log are 32-bit: at most 2^31 - 1 entries, in whole chunks; a wave that finds the log
             // full adds its contributions atomically)
             const unsigned long long want = std::min<unsigned long long>(
                 std::max<unsigned long long>(((unsigned long long)size[g] * perSlot + PMC_RF_LOG_CHUNK - 1) / PMC_RF_LOG_CHUNK, 1ull) * PMC_RF_LOG_CHUNK,
@@ -1273,19 +1275,20 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 continue;
             }
             ctx->rfCap[g] = want;
-            size_t bytes = 0;
-            hipcub::DoubleBuffer<uint32_t> dk(ctx->rfKeys[g][0], ctx->rfKeys[g][1]);
-            hipcub::DoubleBuffer<double> dv(ctx->rfVals[g][0], ctx->rfVals[g][1]);
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dk, dv, (int)std::min<unsigned long long>(want, 0x7FFFFFFFull), PMC_RF_BUCKET_BITS,
-                                                       PMC_RF_BUCKET_BITS + std::max(1, rfSortBits)));
-            bytes = std::max(bytes, ctx->rfTempBytes);
-            for (int h = 0; h < PMC_MAX_GROUPS; ++h)  // (all groups get temporaries of the largest size)
+        }
+    if (rfLogged && ctx->rfTempBytes < pmcRfTempBytes(rfBuckets))
+    {
+        HIP_TRY(hipDeviceSynchronize());
+        for (int h = 0; h < PMC_MAX_GROUPS; ++h)
+            if (ctx->rfTemp[h])
             {
-                release(ctx->rfTemp[h]);
+                hipFree(ctx->rfTemp[h]);
+                auto at = std::find(ctx->rfAllocations.begin(), ctx->rfAllocations.end(), ctx->rfTemp[h]);
+                if (at != ctx->rfAllocations.end()) ctx->rfAllocations.erase(at);
                 ctx->rfTemp[h] = nullptr;
             }
-            ctx->rfTempBytes = bytes;
-        }
+        ctx->rfTempBytes = pmcRfTempBytes(rfBuckets);
+    }
     if (rfLogged)
         for (int g = 0; g < G; ++g)
             if (!ctx->rfTemp[g])
@@ -1300,18 +1303,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         const unsigned long long n = std::min(claimed, ctx->rfCap[g]);
         if (!rfLogged || n == 0) return PMC_OK;
         hipStream_t sg = ctx->groupStream[g];
-        const uint32_t* keys = ctx->rfKeys[g][0];
-        const double* vals = ctx->rfVals[g][0];
-        if (rfBuckets > 1)
-        {
-            hipcub::DoubleBuffer<uint32_t> dk(ctx->rfKeys[g][0], ctx->rfKeys[g][1]);
-            hipcub::DoubleBuffer<double> dv(ctx->rfVals[g][0], ctx->rfVals[g][1]);
-            size_t bytes = ctx->rfTempBytes;
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(ctx->rfTemp[g], bytes, dk, dv, (int)n, PMC_RF_BUCKET_BITS, PMC_RF_BUCKET_BITS + rfSortBits, sg));
-            keys = dk.Current();
-            vals = dv.Current();
-        }
-        HIP_TRY(pmcLaunchRfReduce(ctx->slot, keys, vals, n, rfBuckets, sg));
+        HIP_TRY(pmcLaunchRfFlush(ctx->slot, ctx->rfKeys[g][0], ctx->rfVals[g][0], ctx->rfKeys[g][1], ctx->rfVals[g][1], n, rfBuckets, ctx->rfTemp[g], ctx->numCU, sg));
         return PMC_OK;
     };
     // ---- statistics: every slot group starts with its share of the pool of list blocks, all of them free

@@ -259,6 +259,9 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfReduceKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(sizeof(double) << PMC_RF_BUCKET_BITS));
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfScatterKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(size_t(RF_TILE) * (sizeof(double) + sizeof(uint32_t)) + size_t(2) * RF_MAX_PARTS * sizeof(uint32_t)));
+        if (e != hipSuccess) return e;
     }
     const struct
     {
@@ -426,12 +429,28 @@ extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBas
     return hipGetLastError();
 }
 
-// radiation field: the sorted (or, for a table of one partition, unsorted) log of a generation added to the table
-extern "C" hipError_t pmcLaunchRfReduce(int slot, const uint32_t* keys, const double* vals, unsigned long long n, int numBuckets, hipStream_t stream)
+// radiation field: the log of a generation (n entries in whole chunks) partitioned by key range into (sortedKeys, sortedVals) and
+// added to the table; temp = 2 * numParts + 1 counters (pmcRfTempBytes)
+extern "C" size_t pmcRfTempBytes(int numParts) { return (size_t(2) * size_t(numParts) + 1) * sizeof(unsigned long long); }
+extern "C" int pmcRfMaxParts() { return (int)RF_MAX_PARTS; }
+extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n,
+                                       int numParts, void* temp, int numCU, hipStream_t stream)
 {
+    unsigned long long* cursor = static_cast<unsigned long long*>(temp);
+    unsigned long long* start = cursor + numParts;
+    hipError_t e = hipMemsetAsync(cursor, 0, size_t(numParts) * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    const unsigned long long tiles = n / RF_TILE;
+    const unsigned grid = (unsigned)std::min<unsigned long long>(tiles, (unsigned long long)numCU * 8ull);
+    hipLaunchKernelGGL(rfHistKernel, dim3(std::max(grid, 1u)), dim3(256), 0, stream, keys, n, (uint32_t)numParts, cursor);
+    hipLaunchKernelGGL(rfScanKernel, dim3(1), dim3(1024), 0, stream, cursor, start, (uint32_t)numParts);
+    const size_t sortLds = size_t(RF_TILE) * (sizeof(double) + sizeof(uint32_t)) + size_t(2) * size_t(numParts) * sizeof(uint32_t);
+    const unsigned sortGrid = (unsigned)std::min<unsigned long long>(tiles, (unsigned long long)numCU * 3ull);
+    hipLaunchKernelGGL(rfScatterKernel, dim3(std::max(sortGrid, 1u)), dim3(RF_SORT_BLOCK), sortLds, stream, keys, vals, n, (uint32_t)numParts, cursor, sortedKeys,
+                       sortedVals);
     const size_t lds = sizeof(double) << PMC_RF_BUCKET_BITS;  // (the limit is raised per device in pmcConfigureKernels)
     const unsigned long long blocks = (n + PMC_RF_REDUCE_SPAN - 1) / PMC_RF_REDUCE_SPAN;
-    hipLaunchKernelGGL(rfReduceKernel, dim3((unsigned)blocks), dim3(256), lds, stream, slot, keys, vals, n, (uint32_t)numBuckets);
+    hipLaunchKernelGGL(rfReduceKernel, dim3((unsigned)blocks), dim3(RF_REDUCE_BLOCK), lds, stream, slot, sortedKeys, sortedVals, start, (uint32_t)numParts);
     return hipGetLastError();
 }
 

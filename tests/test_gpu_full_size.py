@@ -248,3 +248,39 @@ def test_config3_full_size_panchromatic():
     eng.run_primary(n // 2, n - n // 2, 77)
     halves = eng.download()
     assert np.allclose(whole, halves, rtol=1e-10, atol=1e-14 * np.abs(whole).max())
+
+
+def test_full_size_radiation_field_log_partition(tmp_path, monkeypatch):
+    """configs[1] with storeRadiationField: 953 688 table entries = 117 partitions of the radiation-field log.  The table from the
+    logged path (rfHistKernel / rfScanKernel / rfScatterKernel / rfReduceKernel behind every generation) against the oracle on the
+    same 3e4 Philox histories (totals 1e-9, elements 1e-6), and 1.5e6 histories (three slot groups, chunks of many waves, long and
+    short runs per partition) against the form that adds every contribution atomically (PMC_RF_ATOMICS=1): totals 1e-11, elements
+    1e-9 -- the two differ in summation order only."""
+    from skirt9_amd.engine import Engine
+    text = open(ski("cfg2.ski")).read()
+    assert 'storeRadiationField="false"' in text
+    path = tmp_path / "cfg2rf.ski"
+    path.write_text(text.replace('storeRadiationField="false"', 'storeRadiationField="true"'))
+    n = 30000
+    sim = Simulation(str(path), num_packets=n).setup()
+    assert sim.radiation_field_size == 953688
+    eng = Engine(sim.scene, 0)
+    eng.run_primary(0, n, 21)
+    got = eng.download_radiation_field()
+    _, ref, _ = O.run_primary_rf(sim, 0, n, O.RNG_PHILOX, seed=21)
+    assert abs(got.sum() - ref.sum()) <= 1e-9 * ref.sum()
+    assert np.array_equal(got > 0, ref > 0)
+    assert (np.abs(got - ref) > 1e-6 * np.abs(ref) + 1e-13 * ref.max()).sum() == 0
+    big = 1500000
+    eng.clear_radiation_field()
+    eng.run_primary(0, big, 22)
+    logged = eng.download_radiation_field()
+    eng.close()
+    monkeypatch.setenv("PMC_RF_ATOMICS", "1")
+    eng = Engine(sim.scene, 0)
+    eng.run_primary(0, big, 22)
+    atomics = eng.download_radiation_field()
+    eng.close()
+    assert abs(logged.sum() - atomics.sum()) <= 1e-11 * atomics.sum()
+    assert np.array_equal(logged > 0, atomics > 0)
+    assert (np.abs(logged - atomics) > 1e-9 * np.abs(atomics) + 1e-15 * atomics.max()).sum() == 0
