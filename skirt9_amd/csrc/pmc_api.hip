@@ -1230,7 +1230,9 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     // walk on average); a wave that finds the log full falls back to atomic adds into the table.
     const int64_t rfSize = ctx->rfSize;
     // (tables beyond 2^25 entries have more partitions than the counting sort's LDS histogram holds: atomics)
-    const int64_t rfParts = (rfSize + (int64_t(1) << PMC_RF_BUCKET_BITS) - 1) >> PMC_RF_BUCKET_BITS;
+    // (the keys of the log count cells in the device numbering: cell_slots of them, padding included)
+    const int64_t rfKeys = D.grid_kind == PMC_GRID_OCTREE ? int64_t(D.cell_slots) * D.rf_num_lambda : rfSize;
+    const int64_t rfParts = (rfKeys + (int64_t(1) << PMC_RF_BUCKET_BITS) - 1) >> PMC_RF_BUCKET_BITS;
     const bool rfLogged = D.rf_store && D.grid_kind == PMC_GRID_OCTREE && rfParts <= pmcRfMaxParts() && getenv("PMC_RF_ATOMICS") == nullptr;
     const int rfBuckets = rfLogged ? int(rfParts) : 0;
     const uint32_t rfPadKey = uint32_t(rfBuckets) << PMC_RF_BUCKET_BITS;
