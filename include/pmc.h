@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PMC_ABI_VERSION 8
+#define PMC_ABI_VERSION 9
 
 enum { PMC_OK = 0, PMC_ERR_INVALID = -1, PMC_ERR_UNSUPPORTED = -2, PMC_ERR_DEVICE = -3, PMC_ERR_NOMEM = -4,
        PMC_ERR_OVERFLOW = -5 /* the pool of statistics-list blocks ran out during the segment (see pmc_run_primary) */ };
@@ -133,6 +133,8 @@ enum { PMC_SOURCE_POINT = 1, PMC_SOURCE_SERSIC = 2, PMC_SOURCE_UNIFORM_BOX = 3, 
 enum { PMC_LAMBDA_OLIGO = 1, PMC_LAMBDA_TABULATED = 2 };
 enum { PMC_BIAS_NONE = 0, PMC_BIAS_LOG = 1, PMC_BIAS_LIN = 2 };
 enum { PMC_SED_TABULATED = 0, PMC_SED_BLACKBODY = 1 };
+enum { PMC_ANGULAR_ISOTROPIC = 0, PMC_ANGULAR_LASER = 1, PMC_ANGULAR_CONICAL = 2, PMC_ANGULAR_NETZER = 3 };
+#define PMC_NETZER_POINTS 400 /* bins of the cumulative table of NetzerAngularDistribution (NetzerAngularDistribution.cpp:17) */
 
 typedef struct pmc_source
 {
@@ -171,6 +173,14 @@ typedef struct pmc_source
        (BlackBodySED.cpp:36-39, PlanckFunction.cpp:24-27) */
     int32_t       sed_kind;         /* PMC_SED_* */
     double        sed_f1, sed_f2, sed_ltot;
+    /* emission direction of a point source (PointSource.cpp:32-43): isotropic, or an axisymmetric distribution about the unit
+       vector angular_axis (AxAngularDistribution.cpp:27-41: the direction is Random::direction(axis, cos theta) with cos theta
+       from the distribution; an emission peel-off packet towards k_obs carries the weight probabilityForDirection(k_obs),
+       PhotonPacket.cpp:78): LaserAngularDistribution.cpp:11-23, ConicalAngularDistribution.cpp:11-37 (angular_cos_delta =
+       cos(openingAngle)), NetzerAngularDistribution.cpp:12-47 (its 401-point cumulative table is rebuilt by the engine) */
+    int32_t       angular_kind;     /* PMC_ANGULAR_* */
+    double        angular_axis[3];
+    double        angular_cos_delta;
 } pmc_source;
 
 /* ---------------------------------------------------------------- instruments ---- */

@@ -623,8 +623,40 @@ namespace
         int interactionCell{-1};
         double interactionDistance{0};
         double interactionOpticalDepth{0};   // cumulative absorption optical depth at the interaction point (explicit absorption)
+        const pmc_source* source{nullptr};   // the source that launched the packet (angular distribution of its emission peel-off packets)
         double luminosity() const { return W / lambda; }
     };
+
+    // ---- axisymmetric angular distributions of a point source (AxAngularDistribution.cpp:27-41)
+    struct NetzerTable
+    {
+        // NetzerAngularDistribution::setupSelfBefore (NetzerAngularDistribution.cpp:12-30; NR::buildLinearGrid, NR.hpp:203-209)
+        double costheta[PMC_NETZER_POINTS + 1], X[PMC_NETZER_POINTS + 1];
+        NetzerTable()
+        {
+            const int n = PMC_NETZER_POINTS;
+            double dx = (+1. - -1.) / n;
+            for (int i = 0; i <= n; i++) costheta[i] = -1. + i * dx;
+            X[0] = 0;
+            for (int i = 1; i < n; i++)
+            {
+                double ct = costheta[i];
+                double sign = ct > 0 ? 1. : -1;
+                X[i] = (1. / 2.) + (2. / 7.) * ct * ct * ct + sign * (3. / 14.) * ct * ct;
+            }
+            X[n] = 1.;
+        }
+    };
+    // probabilityForInclinationCosine: LaserAngularDistribution.cpp:11-16, ConicalAngularDistribution.cpp:19-25,
+    // NetzerAngularDistribution.cpp:34-38
+    double angularProbability(const pmc_source& s, V3 k)
+    {
+        double costheta = s.angular_axis[0] * k.x + s.angular_axis[1] * k.y + s.angular_axis[2] * k.z;
+        if (s.angular_kind == PMC_ANGULAR_LASER) return costheta > 0.99999 ? std::numeric_limits<double>::infinity() : 0.;
+        if (s.angular_kind == PMC_ANGULAR_CONICAL) return std::abs(costheta) > s.angular_cos_delta ? 1.0 / (1.0 - s.angular_cos_delta) : 0.;
+        double sign = costheta > 0 ? 1. : -1;
+        return (6. / 7.) * costheta * (2. * costheta + sign);
+    }
 
     struct Contribution
     {
@@ -811,7 +843,33 @@ namespace
             // OffsetGeometryDecorator::generatePosition (OffsetGeometryDecorator.cpp:33-39)
             if (s.kind != PMC_SOURCE_POINT && (s.position[0] != 0. || s.position[1] != 0. || s.position[2] != 0.))
                 r = V3{r.x + s.position[0], r.y + s.position[1], r.z + s.position[2]};
-            V3 k = randomDirection(rng);
+            V3 k;
+            if (s.kind == PMC_SOURCE_POINT && s.angular_kind != PMC_ANGULAR_ISOTROPIC)
+            {
+                // AxAngularDistribution::generateDirection (AxAngularDistribution.cpp:36-39) with generateInclinationCosine of
+                // LaserAngularDistribution.cpp:20-23, ConicalAngularDistribution.cpp:29-36, NetzerAngularDistribution.cpp:42-45
+                // (Random::cdfLinLin, Random.cpp:201-206)
+                double costheta = 1.;
+                if (s.angular_kind == PMC_ANGULAR_CONICAL)
+                {
+                    double X = rng.uniform();
+                    if (X < 0.5)
+                        costheta = 1.0 - 2.0 * X * (1.0 - s.angular_cos_delta);
+                    else
+                        costheta = 1.0 - 2.0 * s.angular_cos_delta - 2.0 * X * (1.0 - s.angular_cos_delta);
+                }
+                else if (s.angular_kind == PMC_ANGULAR_NETZER)
+                {
+                    static const NetzerTable T;
+                    double X = rng.uniform();
+                    int i = locateClip(T.X, PMC_NETZER_POINTS + 1, X);
+                    costheta = interpolateLinLin(X, T.X[i], T.X[i + 1], T.costheta[i], T.costheta[i + 1]);
+                }
+                k = randomDirectionAbout(rng, V3{s.angular_axis[0], s.angular_axis[1], s.angular_axis[2]}, costheta);
+            }
+            else
+                k = randomDirection(rng);
+            pp.source = &s;
             double Lw = L * w;
             pp.lambda = lambda;
             pp.W = Lw * lambda;
@@ -1329,6 +1387,9 @@ namespace
                     V3 k{ins.kobs[0], ins.kobs[1], ins.kobs[2]};
                     ppp.lambda = pp.lambda;
                     ppp.W = pp.W;
+                    // PhotonPacket::launchEmissionPeelOff (PhotonPacket.cpp:66-85): the bias of an anisotropic emitter
+                    if (pp.source && pp.source->kind == PMC_SOURCE_POINT && pp.source->angular_kind != PMC_ANGULAR_ISOTROPIC)
+                        ppp.W *= angularProbability(*pp.source, k);
                     ppp.D = -(k.x * pp.r.x + k.y * pp.r.y + k.z * pp.r.z);
                     ppp.historyIndex = pp.historyIndex;
                     ppp.nscatt = 0;

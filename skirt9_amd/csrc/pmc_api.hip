@@ -855,8 +855,12 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         for (int h = 0; h < D.num_media; ++h)
         {
             const pmc_medium& mh = scene->media[h];
-            if (!mh.number_density || !mh.lambda_border || !mh.sigma_ext || !mh.sigma_sca || !mh.asymmpar || !mh.sigma_abs || mh.num_lambda < 1)
-                return bail(fail(PMC_ERR_INVALID, "incomplete medium component"));
+            if (!mh.number_density || !mh.lambda_border || !mh.sigma_ext || !mh.sigma_sca || !mh.asymmpar || mh.num_lambda < 1)
+                return bail(fail(PMC_ERR_INVALID, "incomplete medium component " + std::to_string(h)));
+            if (D.explicit_absorption && !mh.sigma_abs) return bail(fail(PMC_ERR_INVALID, "explicit absorption needs pmc_medium::sigma_abs of every component"));
+            // (without explicit absorption the absorption cross sections are loaded with the others but never used)
+            const std::vector<double> noAbs(mh.sigma_abs ? 0 : mh.num_lambda, 0.);
+            const double* const sigmaAbs = mh.sigma_abs ? mh.sigma_abs : noAbs.data();
             for (size_t dev = 0; dev < slots; ++dev)
             {
                 const int64_t m = devToCell.empty() ? int64_t(dev) : int64_t(devToCell[dev]);
@@ -868,7 +872,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
             if ((rc = ctx->upload(mh.lambda_border, mh.num_lambda, &M.lambda_border))) return bail(rc);
             if ((rc = ctx->upload(mh.sigma_ext, mh.num_lambda, &M.sigma_ext))) return bail(rc);
             if ((rc = ctx->upload(mh.sigma_sca, mh.num_lambda, &M.sigma_sca))) return bail(rc);
-            if ((rc = ctx->upload(mh.sigma_abs, mh.num_lambda, &M.sigma_abs))) return bail(rc);
+            if ((rc = ctx->upload(sigmaAbs, mh.num_lambda, &M.sigma_abs))) return bail(rc);
             if ((rc = ctx->upload(mh.asymmpar, mh.num_lambda, &M.asymmpar))) return bail(rc);
         }
     }
@@ -908,6 +912,28 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         Q.sed_f1 = src.sed_f1;
         Q.sed_f2 = src.sed_f2;
         Q.sed_ltot = src.sed_ltot;
+        Q.angular_kind = src.kind == PMC_SOURCE_POINT ? src.angular_kind : PMC_ANGULAR_ISOTROPIC;
+        std::memcpy(Q.angular_axis, src.angular_axis, sizeof(Q.angular_axis));
+        Q.angular_cos_delta = src.angular_cos_delta;
+        if (Q.angular_kind < PMC_ANGULAR_ISOTROPIC || Q.angular_kind > PMC_ANGULAR_NETZER) return bail(fail(PMC_ERR_UNSUPPORTED, "unsupported angular distribution"));
+        if (Q.angular_kind == PMC_ANGULAR_NETZER && !D.netzer_cos)
+        {
+            // NetzerAngularDistribution::setupSelfBefore (NetzerAngularDistribution.cpp:12-30; NR::buildLinearGrid, NR.hpp:203-209)
+            const int n = PMC_NETZER_POINTS;
+            std::vector<double> ct(n + 1), X(n + 1);
+            const double dx = (+1. - -1.) / n;
+            for (int i = 0; i <= n; i++) ct[i] = -1. + i * dx;
+            X[0] = 0;
+            for (int i = 1; i < n; i++)
+            {
+                const double c = ct[i];
+                const double sign = c > 0 ? 1. : -1;
+                X[i] = (1. / 2.) + (2. / 7.) * c * c * c + sign * (3. / 14.) * c * c;
+            }
+            X[n] = 1.;
+            if ((rc = ctx->upload(ct.data(), ct.size(), &D.netzer_cos))) return bail(rc);
+            if ((rc = ctx->upload(X.data(), X.size(), &D.netzer_X))) return bail(rc);
+        }
         if (src.kind == PMC_SOURCE_SERSIC)
         {
             if (src.sersic_n < 2) return bail(fail(PMC_ERR_INVALID, "Sersic source without tables"));
@@ -981,7 +1007,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
                 }
                 ih = jl;
             }
-            D.med[h].mono_ext = mh.sigma_ext[ih], D.med[h].mono_sca = mh.sigma_sca[ih], D.med[h].mono_abs = mh.sigma_abs[ih];
+            D.med[h].mono_ext = mh.sigma_ext[ih], D.med[h].mono_sca = mh.sigma_sca[ih], D.med[h].mono_abs = mh.sigma_abs ? mh.sigma_abs[ih] : 0.;
             D.med[h].mono_asym = mh.asymmpar[ih];
         }
     }

@@ -199,6 +199,9 @@ struct DevSource
     double  bias_min, bias_max;
     int32_t sed_kind;
     double  sed_f1, sed_f2, sed_ltot;
+    int32_t angular_kind;        // PMC_ANGULAR_*: emission direction of a point source
+    double  angular_axis[3];
+    double  angular_cos_delta;
 };
 
 // one medium component of a system of several (pmc.h pmc_scene::media): its cell densities in the DEVICE numbering of the cells and its
@@ -286,6 +289,8 @@ struct DevScene
     // ---- sources (SourceSystem.cpp:100-107: history index h belongs to source i with src_first[i] <= h < src_first[i+1])
     int32_t num_sources;
     DevSource src[PMC_MAX_SOURCES];
+    const double* netzer_cos;    // NetzerAngularDistribution: cos theta grid and cumulative distribution (PMC_NETZER_POINTS + 1 each), or null
+    const double* netzer_X;
     uint64_t src_first[PMC_MAX_SOURCES + 1];
     // ---- instruments
     int32_t num_instruments;

@@ -545,6 +545,10 @@ namespace skh
     {
         std::string type;  // PointSource | GeometricSource
         Vec3 position;
+        // emission direction of a point source: isotropic, or axisymmetric about `angularAxis` (AxAngularDistribution.cpp:12-18: normalised)
+        int angularKind{0};  // PMC_ANGULAR_*
+        Vec3 angularAxis{0., 0., 1.};
+        double angularCosDelta{0.};
         std::unique_ptr<Geometry> geometry;
         double sourceWeight{1.};
         double wavelengthBias{0.5};

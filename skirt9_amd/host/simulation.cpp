@@ -257,7 +257,26 @@ namespace skh
                           || rd.quantity(src, "velocityZ", "velocity", "0");
             if (moving && !_oligo) unsupported("a source with a bulk velocity");
             if (const XmlElement* ad = src.item("angularDistribution"))
-                if (ad->name != "IsotropicAngularDistribution") unsupported("angular distribution " + ad->name);
+            {
+                if (ad->name == "IsotropicAngularDistribution")
+                    _source.angularKind = PMC_ANGULAR_ISOTROPIC;
+                else if (ad->name == "LaserAngularDistribution" || ad->name == "ConicalAngularDistribution" || ad->name == "NetzerAngularDistribution")
+                {
+                    _source.angularKind = ad->name == "LaserAngularDistribution"     ? PMC_ANGULAR_LASER
+                                          : ad->name == "ConicalAngularDistribution" ? PMC_ANGULAR_CONICAL
+                                                                                     : PMC_ANGULAR_NETZER;
+                    // AxAngularDistribution.cpp:12-18, Direction.cpp:61-79: the symmetry axis, normalised
+                    double x = rd.number(*ad, "symmetryX", "0"), y = rd.number(*ad, "symmetryY", "0"), z = rd.number(*ad, "symmetryZ", "1");
+                    const double norm = std::sqrt(x * x + y * y + z * z);
+                    if (!(norm > 0.)) throw std::runtime_error("Symmetry axis direction cannot be null vector");
+                    x /= norm, y /= norm, z /= norm;
+                    _source.angularAxis = Vec3{x, y, z};
+                    if (ad->name == "ConicalAngularDistribution")
+                        _source.angularCosDelta = std::cos(rd.quantity(*ad, "openingAngle", "posangle", ""));
+                }
+                else
+                    unsupported("angular distribution " + ad->name);
+            }
             if (const XmlElement* pp = src.item("polarizationProfile"))
                 if (pp->name != "NoPolarizationProfile") unsupported("polarization profile " + pp->name);
         }
@@ -950,6 +969,9 @@ namespace skh
             s.position[0] = _source.position.x;
             s.position[1] = _source.position.y;
             s.position[2] = _source.position.z;
+            s.angular_kind = _source.angularKind;
+            s.angular_axis[0] = _source.angularAxis.x, s.angular_axis[1] = _source.angularAxis.y, s.angular_axis[2] = _source.angularAxis.z;
+            s.angular_cos_delta = _source.angularCosDelta;
         }
         const Geometry* shape = _source.geometry.get();
         if (auto off = dynamic_cast<const OffsetGeometry*>(shape))

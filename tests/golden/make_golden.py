@@ -24,6 +24,8 @@ Fixtures:
   cfg2ea_*, cfg1nfea_*, cfg1rfea_*   the photon cycle with explicitAbsorption="true" (MonteCarloSimulation.cpp:568-569, 729-733, 751-766;
                MediumSystem.cpp:905-975, 1075-1110): reduced config 2 (forced scattering), the non-forced variant of config 1, and config 1 with
                the radiation field stored (probe file, gzip)
+  cfg1con_*, cfg1netzer_*, cfg1laser_*, cfg2agn_*   point sources with an axisymmetric angular distribution (AxAngularDistribution.cpp:27-41,
+      Conical / Netzer / LaserAngularDistribution.cpp; emission peel-off bias PhotonPacket.cpp:78); cfg2agn: Netzer source in a dust torus (octree)
   cfg2mm_*, cfg2mmea_*, cfg1mmnf_*, cfg3mm_*, cfg1mmrf_*   several medium components with constant cross sections (MediumSystem.cpp:874-887,
                678-730, 796-817): reduced config 2 with a second dust component (Plummer sphere, other mix, mass normalisation), the same
                with explicit absorption, the non-forced variant of config 1 with THREE components, reduced config 3 (panchromatic) with two,
@@ -137,7 +139,7 @@ def main():
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
     for name, scale in (("cfg1", 3.08567758e16), ("cfg1mesh", 3.08567758e16), ("cfg1mesh2", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg2deep", 300 * 3.08567758e16), ("cfg2deeper", 100 * 3.08567758e16), ("cfg3small", None), ("cfg3z", None), ("cfg1nf", None), ("cfg2nf", None),
-                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1sed", None), ("cfg3sed", None), ("cfg3norm", "sed"), ("cfg3disk", "sed"), ("cfg3multi", "sed"), ("cfg3ten", "sed"), ("cfg3flat", "sed"), ("cfg3off", "sed"), ("cfg3plum", "sed"), ("cfg1rf", "rf"), ("cfg3rf", "rf"), ("cfg2ea", None), ("cfg1nfea", None), ("cfg1rfea", "rf"), ("cfg2mm", None), ("cfg2mmea", None), ("cfg1mmnf", None), ("cfg3mm", None), ("cfg1mmrf", "rf"),
+                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1sed", None), ("cfg3sed", None), ("cfg3norm", "sed"), ("cfg3disk", "sed"), ("cfg3multi", "sed"), ("cfg3ten", "sed"), ("cfg3flat", "sed"), ("cfg3off", "sed"), ("cfg3plum", "sed"), ("cfg1rf", "rf"), ("cfg3rf", "rf"), ("cfg2ea", None), ("cfg1nfea", None), ("cfg1rfea", "rf"), ("cfg2mm", None), ("cfg2mmea", None), ("cfg1mmnf", None), ("cfg3mm", None), ("cfg1mmrf", "rf"), ("cfg1con", None), ("cfg1netzer", None), ("cfg1laser", None), ("cfg2agn", None),
                         ("cfg5small", 4000 * 3.08567758e16), ("cfg5dd", "cells"), ("cfg2shell", "cells"), ("cfg2torus", "cells"), ("cfg2ring", "cells"), ("cfg1list", "cells")):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(libpmc):
     assert sorted(engine.SYMBOLS) == declared
     for name in declared:
         assert hasattr(libpmc, name), name
-    assert libpmc.pmc_abi_version() == 8
+    assert libpmc.pmc_abi_version() == 9
 
 
 def test_history_range_is_the_library_function(libpmc):

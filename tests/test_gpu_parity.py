@@ -83,7 +83,7 @@ def _compare_frames(sim, gpu, ref, n):
             assert a[:lay.num_lambda].sum() == n
 
 
-@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg2nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg3file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg3ten.ski", 20000), ("cfg3twelve.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg1long.ski", 5000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000), ("cfg2deep.ski", 20000), ("cfg2deeper.ski", 20000), ("cfg2ea.ski", 20000), ("cfg1nfea.ski", 50000), ("cfg2mm.ski", 20000), ("cfg2mmea.ski", 20000), ("cfg1mmnf.ski", 50000), ("cfg3mm.ski", 20000)])
+@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg2nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg3file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg3ten.ski", 20000), ("cfg3twelve.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg1long.ski", 5000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000), ("cfg2deep.ski", 20000), ("cfg2deeper.ski", 20000), ("cfg2ea.ski", 20000), ("cfg1nfea.ski", 50000), ("cfg2mm.ski", 20000), ("cfg2mmea.ski", 20000), ("cfg1mmnf.ski", 50000), ("cfg3mm.ski", 20000), ("cfg1con.ski", 20000), ("cfg1netzer.ski", 20000), ("cfg1laser.ski", 20000), ("cfg2agn.ski", 20000)])
 def test_photon_loop_matches_oracle(name, n):
     sim = Simulation(ski(name), num_packets=n).setup()
     eng = _engine(sim)

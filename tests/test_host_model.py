@@ -17,7 +17,7 @@ from skirt9_amd.host import Grid, Medium, SceneHead, scene_head  # noqa: E402,F4
 def test_cell_densities_bit_exact(name, cells, nodes):
     sim = Simulation(ski(name + ".ski")).setup()
     head = scene_head(sim)
-    assert head.abi_version == 8
+    assert head.abi_version == 9
     assert head.grid.num_cells == cells
     if nodes:
         assert head.grid.kind == 2 and head.grid.num_nodes == nodes
