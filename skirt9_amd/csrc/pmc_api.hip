@@ -32,11 +32,18 @@ extern "C" int pmcPropBlock(void);
 extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int taskBase, int numTaskRecords, int taskCounter, uint64_t seed, int grid,
                                     int block, size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int grid, size_t ldsBytes,
-                                    hipStream_t stream);
+                                    const PeelRec* sortedRec, const unsigned long long* sortedCount, hipStream_t stream);
 extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, const int* list, int cursor, uint64_t seed, int grid,
                                     size_t ldsBytes, const RfLogArgs* rfLog, hipStream_t stream);
 extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n,
                                        int numParts, void* temp, int numCU, hipStream_t stream);
+extern "C" int pmcPeelHasQueues(int wide, size_t ldsBytes);
+extern "C" const unsigned long long* pmcPeelSortedCount(void* temp);
+extern "C" size_t pmcPeelSortTempBytes();
+extern "C" hipError_t pmcLaunchPeelSort(int slot, int slotBase, int numSlots, int obs, const uint32_t* keys, PeelRec* sorted, int padded, void* temp, int numCU,
+                                        hipStream_t stream);
+extern "C" hipError_t pmcLaunchPeelTileList(int slot, int slotBase, int n, int mode, uint32_t* keys, double* vals, uint32_t* sortedKeys, double* sortedVals,
+                                            void* temp, int* list, int numCU, hipStream_t stream);
 extern "C" size_t pmcRfTempBytes(int numParts);
 extern "C" int pmcRfMaxParts();
 extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, const int* list, int listLen, int maxBlocks,
@@ -44,7 +51,7 @@ extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, 
 extern "C" hipError_t pmcLaunchLaunch(int slot, int slotBase, int numSlots, int group, uint64_t first, uint64_t count, uint64_t seed, int initial,
                                       int maxBlocks, size_t ldsBytes, hipStream_t stream);
 extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int listCounter, int* listOut, const int* listIn,
-                                          int listLen, int maxBlocks, size_t ldsBytes, hipStream_t stream);
+                                          int listLen, int maxBlocks, size_t ldsBytes, const PeelSortArgs* sort, hipStream_t stream);
 extern "C" hipError_t pmcLaunchTrace(int slot, int gridKind, int wide, int uniform, const double r[3], const double k[3],
                                      const double* kdev, int32_t* m, double* ds, int32_t cap, int32_t* n, size_t ldsBytes,
                                      hipStream_t stream);
@@ -124,6 +131,17 @@ struct pmc_ctx
     double* rfVals[PMC_MAX_GROUPS][2]{};
     unsigned long long rfCap[PMC_MAX_GROUPS]{};
     void* rfTemp[PMC_MAX_GROUPS]{};
+    // tuning experiment PMC_EXP_PEEL_TILES: per group the sort buffers and the list of its slots by detector tile
+    uint32_t* expKeys[PMC_MAX_GROUPS][2]{};
+    double* expVals[PMC_MAX_GROUPS][2]{};
+    void* expTemp[PMC_MAX_GROUPS]{};
+    int* expList[PMC_MAX_GROUPS]{};
+    int expCap[PMC_MAX_GROUPS]{};
+    // sorted peel-off records (pmc_device.h PeelRec): per group the records in slot order and in tile order, the keys, the sort's counters
+    PeelRec* peelRec[PMC_MAX_GROUPS][2]{};
+    uint32_t* peelKeys[PMC_MAX_GROUPS]{};
+    void* peelTemp[PMC_MAX_GROUPS]{};
+    int peelCap[PMC_MAX_GROUPS]{};
     size_t rfTempBytes{0};
 
     template<typename T> int upload(const T* host, size_t count, const T** out)
@@ -1237,6 +1255,17 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     // transition kernel retires the histories that end (nothing is left to launch into their slots), the cycle start kernel
     // writes the list of the generation after it into the other half of TaskArrays::liveList.
     bool listBuilt[PMC_MAX_GROUPS] = {false, false, false, false};
+    // sorted peel-off records (pmc_device.h PeelRec): an octree whose peel-off kernel runs with task queues, ONE observer (its records
+    // are written by the cycle start kernel in slot order, sorted by detector tile, and read in tile order by the peel-off kernel)
+    bool peelSorted[PMC_MAX_GROUPS] = {false, false, false, false};
+    int peelSortObs = -1;
+    if (D.grid_kind == PMC_GRID_OCTREE && getenv("PMC_NO_PEEL_SORT") == nullptr
+        && pmcPeelHasQueues((ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), ctx->walkLds))
+    {
+        int observers = 0;
+        for (int i = 0; i < D.num_instruments; ++i) observers += D.inst[i].same_observer ? 0 : 1;
+        if (observers == 1) peelSortObs = 0;
+    }
     int listHalf[PMC_MAX_GROUPS] = {0, 0, 0, 0};  // the half of liveList that holds the group's current list
     int listTasksPerLane = 1;  // walks per lane that size the walk kernels' grids in a sparse generation
     if (const char* env = getenv("PMC_LIST_TASKS_PER_LANE")) listTasksPerLane = std::max(1, atoi(env));
@@ -1251,6 +1280,20 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             haveWalk[g] = false;
         }
     }
+    if (peelSortObs >= 0)
+        for (int g = 0; g < G; ++g)
+        {
+            const int padded = (size[g] + 4095) / 4096 * 4096;
+            if (ctx->peelCap[g] >= padded) continue;
+            HIP_TRY(hipDeviceSynchronize());
+            int rc;
+            if ((rc = ctx->allocate<PeelRec>(padded, &ctx->peelRec[g][1], false, &ctx->rfAllocations))) return rc;
+            if ((rc = ctx->allocate<uint32_t>(padded, &ctx->peelKeys[g], false, &ctx->rfAllocations))) return rc;
+            uint8_t* t = nullptr;
+            if ((rc = ctx->allocate<uint8_t>(pmcPeelSortTempBytes(), &t, false, &ctx->rfAllocations))) return rc;
+            ctx->peelTemp[g] = t;
+            ctx->peelCap[g] = padded;
+        }
     // ---- radiation field on an octree: the contributions of a generation go to a log per slot group (pmc_device.h RfLogArgs),
     // which is partitioned by key range and summed after the generation.  128 entries per slot (config 2: 60 per propagation
     // walk on average); a wave that finds the log full falls back to atomic adds into the table.
@@ -1387,17 +1430,72 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 if (serialWalks) sp = sg;
                 const int* list = listIn;
                 const int numTasks = list ? listLen : size[g];
+                const int* peelList = list;
+                const int expTiles = getenv("PMC_EXP_PEEL_TILES") ? atoi(getenv("PMC_EXP_PEEL_TILES")) : 0;
+                if (expTiles && !list && D.num_instruments == 1)
+                {
+                    const int padded = (size[g] + 4095) / 4096 * 4096;
+                    if (ctx->expCap[g] < padded)
+                    {
+                        HIP_TRY(hipDeviceSynchronize());
+                        int rc;
+                        for (int k = 0; k < 2; ++k)
+                        {
+                            if ((rc = ctx->allocate<uint32_t>(padded, &ctx->expKeys[g][k], false, &ctx->rfAllocations))) return rc;
+                            if ((rc = ctx->allocate<double>(padded, &ctx->expVals[g][k], false, &ctx->rfAllocations))) return rc;
+                        }
+                        uint8_t* t = nullptr;
+                        if ((rc = ctx->allocate<uint8_t>(pmcRfTempBytes(4096), &t, false, &ctx->rfAllocations))) return rc;
+                        ctx->expTemp[g] = t;
+                        if ((rc = ctx->allocate<int>(padded, &ctx->expList[g], false, &ctx->rfAllocations))) return rc;
+                        ctx->expCap[g] = padded;
+                    }
+                    HIP_TRY(hipStreamWaitEvent(sp, ctx->evA[g], 0));
+                    HIP_TRY(pmcLaunchPeelTileList(ctx->slot, base[g], size[g], expTiles, ctx->expKeys[g][0], ctx->expVals[g][0], ctx->expKeys[g][1], ctx->expVals[g][1],
+                                                  ctx->expTemp[g], ctx->expList[g], ctx->numCU, sp));
+                    peelList = ctx->expList[g];
+                }
+                const int* propList = list;
+                const int expProp = getenv("PMC_EXP_PROP_TILES") ? atoi(getenv("PMC_EXP_PROP_TILES")) : 0;
+                if (expProp && !list)
+                {
+                    // (tuning experiment: the same for the propagation walks, keyed by direction cone and start shell; second set of buffers = group g + 2)
+                    const int gb = (g + 2) % PMC_MAX_GROUPS;
+                    const int padded = (size[g] + 4095) / 4096 * 4096;
+                    if (ctx->expCap[gb] < padded)
+                    {
+                        HIP_TRY(hipDeviceSynchronize());
+                        int rc;
+                        for (int k = 0; k < 2; ++k)
+                        {
+                            if ((rc = ctx->allocate<uint32_t>(padded, &ctx->expKeys[gb][k], false, &ctx->rfAllocations))) return rc;
+                            if ((rc = ctx->allocate<double>(padded, &ctx->expVals[gb][k], false, &ctx->rfAllocations))) return rc;
+                        }
+                        uint8_t* t = nullptr;
+                        if ((rc = ctx->allocate<uint8_t>(pmcRfTempBytes(4096), &t, false, &ctx->rfAllocations))) return rc;
+                        ctx->expTemp[gb] = t;
+                        if ((rc = ctx->allocate<int>(padded, &ctx->expList[gb], false, &ctx->rfAllocations))) return rc;
+                        ctx->expCap[gb] = padded;
+                    }
+                    HIP_TRY(pmcLaunchPeelTileList(ctx->slot, base[g], size[g], expProp, ctx->expKeys[gb][0], ctx->expVals[gb][0], ctx->expKeys[gb][1], ctx->expVals[gb][1],
+                                                  ctx->expTemp[gb], ctx->expList[gb], ctx->numCU, sg));
+                    propList = ctx->expList[gb];
+                }
                 const int peelLanes = pmcPeelBlock() * listTasksPerLane, propLanes = pmcPropBlock() * listTasksPerLane;
                 const int peelGrid = list ? std::max(1, std::min(ctx->peelGrid, (numTasks + peelLanes - 1) / peelLanes)) : ctx->peelGrid;
                 const int propGrid = list ? std::max(1, std::min(ctx->grid, (numTasks + propLanes - 1) / propLanes)) : ctx->grid;
                 HIP_TRY(hipStreamWaitEvent(sp, ctx->evA[g], 0));
                 for (int i = 0; i < D.num_instruments; ++i)
                     if (!D.inst[i].same_observer)
-                        HIP_TRY(pmcLaunchPeel(ctx->slot, (ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), base[g], numTasks, list, PMC_CTR_TASK(g, 1 + i), i, peelGrid, ctx->walkLds, sp));
+                    {
+                        const bool sorted = peelSorted[g] && !list && i == peelSortObs;
+                        HIP_TRY(pmcLaunchPeel(ctx->slot, (ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), base[g], numTasks, sorted ? nullptr : peelList, PMC_CTR_TASK(g, 1 + i), i,
+                                              peelGrid, ctx->walkLds, sorted ? ctx->peelRec[g][1] : nullptr, sorted ? pmcPeelSortedCount(ctx->peelTemp[g]) : nullptr, sp));
+                    }
                 HIP_TRY(hipEventRecord(ctx->evJoin[g], sp));
                 RfLogArgs log = {ctx->rfKeys[g][0], ctx->rfVals[g][0], rfLogged ? ctx->rfCap[g] : 0ull, PMC_CTR_RFLOG(g), rfPadKey};
                 if (serialWalks) HIP_TRY(hipEventRecord(ctx->evProp[g], sg));  // (in series: the propagation kernel starts where the peel-off kernels end)
-                HIP_TRY(pmcLaunchProp(ctx->slot, ctx->wide, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0) | (D.num_media > 1 ? 4 : 0), base[g], numTasks, list, PMC_CTR_TASK(g, 0), seed, propGrid, ctx->walkLds, &log, sg));
+                HIP_TRY(pmcLaunchProp(ctx->slot, ctx->wide, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0) | (D.num_media > 1 ? 4 : 0), base[g], numTasks, propList, PMC_CTR_TASK(g, 0), seed, propGrid, ctx->walkLds, &log, sg));
                 if (!serialWalks) HIP_TRY(hipEventRecord(ctx->evProp[g], sg));
                 HIP_TRY(hipStreamWaitEvent(sg, ctx->evJoin[g], 0));
             }
@@ -1423,8 +1521,16 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         const bool buildList = sparseLists && !initial && (listIn || ctx->pinned[g] < (unsigned long long)(size[g] / 2));
         if (listIn) listHalf[g] ^= 1;
         int* const listOut = D.tasks.liveList + int64_t(listHalf[g]) * D.slots.num_slots + base[g];
+        const bool sortNow = peelSortObs >= 0 && !buildList && !listIn;
+        const double gdx = D.gx1 - D.gx0, gdy = D.gy1 - D.gy0, gdz = D.gz1 - D.gz0;
+        const PeelSortArgs sortArgs = {ctx->peelKeys[g], uint32_t(PMC_PEEL_TILES * PMC_PEEL_TILES) << PMC_RF_BUCKET_BITS, peelSortObs, (size[g] + 4095) / 4096 * 4096,
+                                       {0.5 * (D.gx0 + D.gx1), 0.5 * (D.gy0 + D.gy1), 0.5 * (D.gz0 + D.gz1)},
+                                       PMC_PEEL_TILES / std::sqrt(gdx * gdx + gdy * gdy + gdz * gdz)};
         HIP_TRY(pmcLaunchCycleStart(ctx->slot, D.grid_kind, base[g], size[g], buildList ? PMC_CTR_LIST(g) : -1, listOut, listIn, listLen, cycleBlocks,
-                                    ctx->walkLds, sg));
+                                    ctx->walkLds, sortNow ? &sortArgs : nullptr, sg));
+        if (sortNow)
+            HIP_TRY(pmcLaunchPeelSort(ctx->slot, base[g], size[g], peelSortObs, ctx->peelKeys[g], ctx->peelRec[g][1], (size[g] + 4095) / 4096 * 4096, ctx->peelTemp[g], ctx->numCU, sg));
+        peelSorted[g] = sortNow;
         listBuilt[g] = buildList;
         HIP_TRY(hipEventRecord(ctx->evC[g], sg));
         HIP_TRY(hipMemcpyAsync(ctx->pinned + g, ctr + PMC_CTR_LIVE(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));

@@ -347,6 +347,39 @@ struct RfLogArgs
     int32_t cursor;          // index of the log's cursor in DevScene::counters
     uint32_t padKey;         // key of the entries that fill up a wave's last chunk (beyond every table index)
 };
+// Octree, one observer: the peel-off walks of a generation as 64-byte records SORTED by the tile of the detector plane their start
+// position projects to.  The cycle start kernel writes the walks' start states to the task arrays as ever, and a sort key per slot of the
+// group; a counting sort on the tile (rfHistKernel / rfScanKernel / peelRecordScatterKernel) gathers the start states of the slots that
+// have a walk into records in tile order; the
+// peel-off kernel takes them in that order: its task loads are coalesced, and the walks in flight on the chip at any moment run
+// through one slab of the grid (parallel lines of sight from neighbouring tiles) -- the L2s hold it.
+struct PeelRec
+{
+    double rx, ry, rz;   // start of the walk (inside the grid)
+    double ds;           // exit distance of the first cell
+    double target;       // the walk stops in the first segment with tau > target
+    uint64_t pidx;       // packed fine lower-corner indices of the first cell
+    uint32_t cell, bits; // first cell; exit axis (bits 2-3), size exponent (8-11) as in TaskArrays::bits
+    int32_t slot;        // where the optical depth goes (SlotArrays::ptau)
+    uint32_t pad;
+};
+struct PeelSortArgs  // cycle start kernel; keys == nullptr: no sort
+{
+    uint32_t* keys;      // [numSlots rounded up to whole sort tiles] tile << PMC_RF_BUCKET_BITS, or padKey (no walk)
+    uint32_t padKey;
+    int32_t obs;         // the observer (first instrument of its group)
+    int32_t padded;      // entries of `keys` (whole sort tiles): the ones beyond the group's slots are set to padKey
+    double centre[3];    // of the grid
+    double scale;        // PMC_PEEL_TILES / the grid's diagonal
+};
+struct PeelSortedArgs  // peel-off kernel; rec == nullptr: task records from TaskArrays
+{
+    const PeelRec* rec;
+    const unsigned long long* count;  // number of sorted records (device memory)
+};
+#ifndef PMC_PEEL_TILES
+#define PMC_PEEL_TILES 32  // tiles per axis of the detector plane (PMC_PEEL_TILES^2 sort partitions)
+#endif
 #ifndef PMC_VORO_CONES
 #define PMC_VORO_CONES 192  // direction cones of DevScene::vcull: 48, or 192 (every cone divided at the midpoints of its edges)
 #endif

@@ -380,8 +380,40 @@ extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int tas
 }
 
 // octree: the peel-off walks towards observer `obs` of the slots [slotBase, slotBase + numSlots)
+// does the peel-off kernel of this octree run with task queues (the form that can take sorted records)?
+extern "C" int pmcPeelHasQueues(int wide, size_t ldsBytes)
+{
+    static const bool first = getenv("PMC_PEEL_V1") != nullptr;
+    return !first && (wide & 2) == 0 && ((ldsBytes + 15) & ~size_t(15)) + pmcPeelQueueBytes() <= size_t(160) * 1024;
+}
+// the peel-off walks of a group (keys in slot order, as many as whole sort tiles hold = `padded`; start states in the task arrays) -> records sorted by tile;
+// temp: pmcPeelSortTempBytes(); the number of sorted records is left at pmcPeelSortedCount(temp)
+constexpr int PEEL_SORT_GROUPS = 768;
+constexpr int PEEL_SORT_PARTS = PMC_PEEL_TILES * PMC_PEEL_TILES;
+extern "C" size_t pmcPeelSortTempBytes()
+{
+    // counters (totals, then starts: 2 * parts + 1) followed by the matrix [groups][parts]
+    return (size_t(2) * PEEL_SORT_PARTS + 2) * sizeof(unsigned long long) + size_t(PEEL_SORT_GROUPS) * PEEL_SORT_PARTS * sizeof(uint32_t);
+}
+extern "C" const unsigned long long* pmcPeelSortedCount(void* temp) { return static_cast<const unsigned long long*>(temp) + 2 * PEEL_SORT_PARTS; }
+extern "C" hipError_t pmcLaunchPeelSort(int slot, int slotBase, int numSlots, int obs, const uint32_t* keys, PeelRec* sorted, int padded, void* temp, int numCU,
+                                        hipStream_t stream)
+{
+    const int numParts = PEEL_SORT_PARTS;
+    unsigned long long* totals = static_cast<unsigned long long*>(temp);
+    unsigned long long* start = totals + numParts;
+    uint32_t* matrix = reinterpret_cast<uint32_t*>(totals + 2 * numParts + 2);
+    const unsigned long long tiles = (unsigned long long)padded / RF_TILE;
+    const unsigned groups = (unsigned)std::max<unsigned long long>(1ull, std::min<unsigned long long>(tiles, (unsigned long long)PEEL_SORT_GROUPS));
+    hipLaunchKernelGGL(peelSortCountKernel, dim3(groups), dim3(RF_SORT_BLOCK), 0, stream, keys, (unsigned long long)padded, (uint32_t)numParts, matrix);
+    hipLaunchKernelGGL(peelSortOffsetsKernel, dim3((numParts + 15) / 16), dim3(256), 0, stream, matrix, groups, (uint32_t)numParts, totals);
+    hipLaunchKernelGGL(rfScanKernel, dim3(1), dim3(1024), 0, stream, totals, start, (uint32_t)numParts);
+    hipLaunchKernelGGL(peelSortScatterKernel, dim3(groups), dim3(RF_SORT_BLOCK), 0, stream, slot, slotBase, obs, keys, (unsigned long long)padded, (uint32_t)numParts, matrix,
+                       start, sorted);
+    return hipGetLastError();
+}
 extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int grid, size_t ldsBytes,
-                                    hipStream_t stream)
+                                    const PeelRec* sortedRec, const unsigned long long* sortedCount, hipStream_t stream)
 {
     static const bool first = getenv("PMC_PEEL_V1") != nullptr;  // (tuning aid: the form with service rounds)
     // (`wide` bit 1: several medium components -- the form with service rounds)
@@ -398,8 +430,9 @@ extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlo
         // (the waves' task queues follow the grid tables in LDS)
         auto kernel = wide ? walkPeelKernel2<true> : walkPeelKernel2<false>;
         const size_t queueOffset = (ldsBytes + 15) & ~size_t(15);
+        const PeelSortedArgs sorted = {sortedRec, sortedCount};
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PEEL_BLOCK), queueOffset + pmcPeelQueueBytes(), stream, slot, slotBase, numSlots, cursor, obs,
-                           (int)queueOffset, list);
+                           (int)queueOffset, list, sorted);
     }
     return hipGetLastError();
 }
@@ -433,8 +466,10 @@ extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBas
 // added to the table; temp = 2 * numParts + 1 counters (pmcRfTempBytes)
 extern "C" size_t pmcRfTempBytes(int numParts) { return (size_t(2) * size_t(numParts) + 1) * sizeof(unsigned long long); }
 extern "C" int pmcRfMaxParts() { return (int)RF_MAX_PARTS; }
-extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n,
-                                       int numParts, void* temp, int numCU, hipStream_t stream)
+// the counting sort of (key, value) pairs on key >> PMC_RF_BUCKET_BITS: n entries in whole tiles of RF_TILE -> (sortedKeys, sortedVals), pad
+// keys dropped; temp = 2 * numParts + 1 counters: the partition starts are left at temp + numParts (numParts + 1 of them)
+static hipError_t launchPartition(const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n, int numParts,
+                                  void* temp, int numCU, hipStream_t stream)
 {
     unsigned long long* cursor = static_cast<unsigned long long*>(temp);
     unsigned long long* start = cursor + numParts;
@@ -448,9 +483,31 @@ extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const dou
     const unsigned sortGrid = (unsigned)std::min<unsigned long long>(tiles, (unsigned long long)numCU * 3ull);
     hipLaunchKernelGGL(rfScatterKernel, dim3(std::max(sortGrid, 1u)), dim3(RF_SORT_BLOCK), sortLds, stream, keys, vals, n, (uint32_t)numParts, cursor, sortedKeys,
                        sortedVals);
+    return hipGetLastError();
+}
+extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n,
+                                       int numParts, void* temp, int numCU, hipStream_t stream)
+{
+    hipError_t e = launchPartition(keys, vals, sortedKeys, sortedVals, n, numParts, temp, numCU, stream);
+    if (e != hipSuccess) return e;
+    const unsigned long long* start = static_cast<const unsigned long long*>(temp) + numParts;
     const size_t lds = sizeof(double) << PMC_RF_BUCKET_BITS;  // (the limit is raised per device in pmcConfigureKernels)
     const unsigned long long blocks = (n + PMC_RF_REDUCE_SPAN - 1) / PMC_RF_REDUCE_SPAN;
     hipLaunchKernelGGL(rfReduceKernel, dim3((unsigned)blocks), dim3(RF_REDUCE_BLOCK), lds, stream, slot, sortedKeys, sortedVals, start, (uint32_t)numParts);
+    return hipGetLastError();
+}
+// tuning experiment (PMC_EXP_PEEL_TILES = mode): the slots [slotBase, slotBase + n) listed by detector tile into `list`; keys / vals / sorted*:
+// room for n rounded up to whole tiles of 4096 entries; temp: pmcRfTempBytes(4096)
+extern "C" hipError_t pmcLaunchPeelTileList(int slot, int slotBase, int n, int mode, uint32_t* keys, double* vals, uint32_t* sortedKeys, double* sortedVals,
+                                            void* temp, int* list, int numCU, hipStream_t stream)
+{
+    const int padded = int((unsigned(n) + RF_TILE - 1) / RF_TILE * RF_TILE);
+    const int numParts = 4096;
+    hipLaunchKernelGGL(peelTileKeysKernel, dim3(numCU * 4), dim3(256), 0, stream, slot, slotBase, n, padded, mode, keys, vals, uint32_t(numParts) << PMC_RF_BUCKET_BITS);
+    hipError_t e = launchPartition(keys, vals, sortedKeys, sortedVals, (unsigned long long)padded, numParts, temp, numCU, stream);
+    if (e != hipSuccess) return e;
+    const unsigned long long* start = static_cast<const unsigned long long*>(temp) + numParts;
+    hipLaunchKernelGGL(peelListKernel, dim3(numCU * 4), dim3(256), 0, stream, sortedVals, start, (uint32_t)numParts, list);
     return hipGetLastError();
 }
 
@@ -487,15 +544,17 @@ extern "C" hipError_t pmcLaunchLaunch(int slot, int slotBase, int numSlots, int 
 
 // the walks of the cycle that every live slot of the group is about to start (task records)
 extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int listCounter, int* listOut, const int* listIn,
-                                          int listLen, int maxBlocks, size_t ldsBytes, hipStream_t stream)
+                                          int listLen, int maxBlocks, size_t ldsBytes, const PeelSortArgs* sort, hipStream_t stream)
 {
+    const PeelSortArgs none = {nullptr, 0u, -1, 0, {0., 0., 0.}, 0.};
+    const PeelSortArgs ps = sort ? *sort : none;
     const int grid = std::max(1, std::min(((listIn ? listLen : numSlots) + 255) / 256, maxBlocks));
     if (gridKind == PMC_GRID_OCTREE)
-        hipLaunchKernelGGL(cycleStartKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter, listOut, listIn, listLen);
+        hipLaunchKernelGGL(cycleStartKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter, listOut, listIn, listLen, ps);
     else if (gridKind == PMC_GRID_VORONOI)
-        hipLaunchKernelGGL(cycleStartKernel<GRID_VORO>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter, listOut, listIn, listLen);
+        hipLaunchKernelGGL(cycleStartKernel<GRID_VORO>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter, listOut, listIn, listLen, ps);
     else
-        hipLaunchKernelGGL(cycleStartKernel<GRID_CART>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter, listOut, listIn, listLen);
+        hipLaunchKernelGGL(cycleStartKernel<GRID_CART>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter, listOut, listIn, listLen, ps);
     return hipGetLastError();
 }
 

@@ -284,3 +284,27 @@ def test_full_size_radiation_field_log_partition(tmp_path, monkeypatch):
     assert abs(logged.sum() - atomics.sum()) <= 1e-11 * atomics.sum()
     assert np.array_equal(logged > 0, atomics > 0)
     assert (np.abs(logged - atomics) > 1e-9 * np.abs(atomics) + 1e-15 * atomics.max()).sum() == 0
+
+
+def test_full_size_sorted_peel_records_change_nothing(full, monkeypatch):
+    """The peel-off walks of a generation run from records sorted by detector tile (pmc_device.h PeelRec; one observer, octree); PMC_NO_PEEL_SORT=1
+    runs them from the task arrays in slot order as in rounds 1-3.  Same histories, same walks: the counted work is identical, the integer
+    counts are identical, the sums agree to summation order."""
+    from skirt9_amd.engine import Engine
+    sim, eng = full
+    n = 1000000
+    eng.clear()
+    eng.reset_counters()
+    eng.run_primary(0, n, 31)
+    a, ca = eng.download(), eng.counters()
+    monkeypatch.setenv("PMC_NO_PEEL_SORT", "1")
+    plain = Engine(sim.scene, 0)
+    plain.run_primary(0, n, 31)
+    b, cb = plain.download(), plain.counters()
+    plain.close()
+    assert ca["cell_visits"] == cb["cell_visits"] and ca["scatterings"] == cb["scatterings"] and ca["histories"] == cb["histories"] == n
+    lay = sim.layout(0)
+    w0 = slice(lay.wsed_offset, lay.wsed_offset + lay.num_lambda)
+    assert np.array_equal(a[w0], b[w0])
+    assert abs(a.sum() - b.sum()) <= 1e-11 * np.abs(b).sum()
+    assert (np.abs(a - b) > 1e-9 * np.abs(b) + 1e-15 * np.abs(b).max()).sum() == 0
