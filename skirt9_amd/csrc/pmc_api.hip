@@ -42,8 +42,6 @@ extern "C" const unsigned long long* pmcPeelSortedCount(void* temp);
 extern "C" size_t pmcPeelSortTempBytes();
 extern "C" hipError_t pmcLaunchPeelSort(int slot, int slotBase, int numSlots, int obs, const uint32_t* keys, PeelRec* sorted, int padded, void* temp, int numCU,
                                         hipStream_t stream);
-extern "C" hipError_t pmcLaunchPeelTileList(int slot, int slotBase, int n, int mode, uint32_t* keys, double* vals, uint32_t* sortedKeys, double* sortedVals,
-                                            void* temp, int* list, int numCU, hipStream_t stream);
 extern "C" size_t pmcRfTempBytes(int numParts);
 extern "C" int pmcRfMaxParts();
 extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, const int* list, int listLen, int maxBlocks,
@@ -131,12 +129,6 @@ struct pmc_ctx
     double* rfVals[PMC_MAX_GROUPS][2]{};
     unsigned long long rfCap[PMC_MAX_GROUPS]{};
     void* rfTemp[PMC_MAX_GROUPS]{};
-    // tuning experiment PMC_EXP_PEEL_TILES: per group the sort buffers and the list of its slots by detector tile
-    uint32_t* expKeys[PMC_MAX_GROUPS][2]{};
-    double* expVals[PMC_MAX_GROUPS][2]{};
-    void* expTemp[PMC_MAX_GROUPS]{};
-    int* expList[PMC_MAX_GROUPS]{};
-    int expCap[PMC_MAX_GROUPS]{};
     // sorted peel-off records (pmc_device.h PeelRec): per group the records in slot order and in tile order, the keys, the sort's counters
     PeelRec* peelRec[PMC_MAX_GROUPS][2]{};
     uint32_t* peelKeys[PMC_MAX_GROUPS]{};
@@ -1430,57 +1422,6 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 if (serialWalks) sp = sg;
                 const int* list = listIn;
                 const int numTasks = list ? listLen : size[g];
-                const int* peelList = list;
-                const int expTiles = getenv("PMC_EXP_PEEL_TILES") ? atoi(getenv("PMC_EXP_PEEL_TILES")) : 0;
-                if (expTiles && !list && D.num_instruments == 1)
-                {
-                    const int padded = (size[g] + 4095) / 4096 * 4096;
-                    if (ctx->expCap[g] < padded)
-                    {
-                        HIP_TRY(hipDeviceSynchronize());
-                        int rc;
-                        for (int k = 0; k < 2; ++k)
-                        {
-                            if ((rc = ctx->allocate<uint32_t>(padded, &ctx->expKeys[g][k], false, &ctx->rfAllocations))) return rc;
-                            if ((rc = ctx->allocate<double>(padded, &ctx->expVals[g][k], false, &ctx->rfAllocations))) return rc;
-                        }
-                        uint8_t* t = nullptr;
-                        if ((rc = ctx->allocate<uint8_t>(pmcRfTempBytes(4096), &t, false, &ctx->rfAllocations))) return rc;
-                        ctx->expTemp[g] = t;
-                        if ((rc = ctx->allocate<int>(padded, &ctx->expList[g], false, &ctx->rfAllocations))) return rc;
-                        ctx->expCap[g] = padded;
-                    }
-                    HIP_TRY(hipStreamWaitEvent(sp, ctx->evA[g], 0));
-                    HIP_TRY(pmcLaunchPeelTileList(ctx->slot, base[g], size[g], expTiles, ctx->expKeys[g][0], ctx->expVals[g][0], ctx->expKeys[g][1], ctx->expVals[g][1],
-                                                  ctx->expTemp[g], ctx->expList[g], ctx->numCU, sp));
-                    peelList = ctx->expList[g];
-                }
-                const int* propList = list;
-                const int expProp = getenv("PMC_EXP_PROP_TILES") ? atoi(getenv("PMC_EXP_PROP_TILES")) : 0;
-                if (expProp && !list)
-                {
-                    // (tuning experiment: the same for the propagation walks, keyed by direction cone and start shell; second set of buffers = group g + 2)
-                    const int gb = (g + 2) % PMC_MAX_GROUPS;
-                    const int padded = (size[g] + 4095) / 4096 * 4096;
-                    if (ctx->expCap[gb] < padded)
-                    {
-                        HIP_TRY(hipDeviceSynchronize());
-                        int rc;
-                        for (int k = 0; k < 2; ++k)
-                        {
-                            if ((rc = ctx->allocate<uint32_t>(padded, &ctx->expKeys[gb][k], false, &ctx->rfAllocations))) return rc;
-                            if ((rc = ctx->allocate<double>(padded, &ctx->expVals[gb][k], false, &ctx->rfAllocations))) return rc;
-                        }
-                        uint8_t* t = nullptr;
-                        if ((rc = ctx->allocate<uint8_t>(pmcRfTempBytes(4096), &t, false, &ctx->rfAllocations))) return rc;
-                        ctx->expTemp[gb] = t;
-                        if ((rc = ctx->allocate<int>(padded, &ctx->expList[gb], false, &ctx->rfAllocations))) return rc;
-                        ctx->expCap[gb] = padded;
-                    }
-                    HIP_TRY(pmcLaunchPeelTileList(ctx->slot, base[g], size[g], expProp, ctx->expKeys[gb][0], ctx->expVals[gb][0], ctx->expKeys[gb][1], ctx->expVals[gb][1],
-                                                  ctx->expTemp[gb], ctx->expList[gb], ctx->numCU, sg));
-                    propList = ctx->expList[gb];
-                }
                 const int peelLanes = pmcPeelBlock() * listTasksPerLane, propLanes = pmcPropBlock() * listTasksPerLane;
                 const int peelGrid = list ? std::max(1, std::min(ctx->peelGrid, (numTasks + peelLanes - 1) / peelLanes)) : ctx->peelGrid;
                 const int propGrid = list ? std::max(1, std::min(ctx->grid, (numTasks + propLanes - 1) / propLanes)) : ctx->grid;
@@ -1489,13 +1430,13 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                     if (!D.inst[i].same_observer)
                     {
                         const bool sorted = peelSorted[g] && !list && i == peelSortObs;
-                        HIP_TRY(pmcLaunchPeel(ctx->slot, (ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), base[g], numTasks, sorted ? nullptr : peelList, PMC_CTR_TASK(g, 1 + i), i,
+                        HIP_TRY(pmcLaunchPeel(ctx->slot, (ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), base[g], numTasks, sorted ? nullptr : list, PMC_CTR_TASK(g, 1 + i), i,
                                               peelGrid, ctx->walkLds, sorted ? ctx->peelRec[g][1] : nullptr, sorted ? pmcPeelSortedCount(ctx->peelTemp[g]) : nullptr, sp));
                     }
                 HIP_TRY(hipEventRecord(ctx->evJoin[g], sp));
                 RfLogArgs log = {ctx->rfKeys[g][0], ctx->rfVals[g][0], rfLogged ? ctx->rfCap[g] : 0ull, PMC_CTR_RFLOG(g), rfPadKey};
                 if (serialWalks) HIP_TRY(hipEventRecord(ctx->evProp[g], sg));  // (in series: the propagation kernel starts where the peel-off kernels end)
-                HIP_TRY(pmcLaunchProp(ctx->slot, ctx->wide, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0) | (D.num_media > 1 ? 4 : 0), base[g], numTasks, propList, PMC_CTR_TASK(g, 0), seed, propGrid, ctx->walkLds, &log, sg));
+                HIP_TRY(pmcLaunchProp(ctx->slot, ctx->wide, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0) | (D.num_media > 1 ? 4 : 0), base[g], numTasks, list, PMC_CTR_TASK(g, 0), seed, propGrid, ctx->walkLds, &log, sg));
                 if (!serialWalks) HIP_TRY(hipEventRecord(ctx->evProp[g], sg));
                 HIP_TRY(hipStreamWaitEvent(sg, ctx->evJoin[g], 0));
             }

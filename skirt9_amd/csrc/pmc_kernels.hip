@@ -496,21 +496,6 @@ extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const dou
     hipLaunchKernelGGL(rfReduceKernel, dim3((unsigned)blocks), dim3(RF_REDUCE_BLOCK), lds, stream, slot, sortedKeys, sortedVals, start, (uint32_t)numParts);
     return hipGetLastError();
 }
-// tuning experiment (PMC_EXP_PEEL_TILES = mode): the slots [slotBase, slotBase + n) listed by detector tile into `list`; keys / vals / sorted*:
-// room for n rounded up to whole tiles of 4096 entries; temp: pmcRfTempBytes(4096)
-extern "C" hipError_t pmcLaunchPeelTileList(int slot, int slotBase, int n, int mode, uint32_t* keys, double* vals, uint32_t* sortedKeys, double* sortedVals,
-                                            void* temp, int* list, int numCU, hipStream_t stream)
-{
-    const int padded = int((unsigned(n) + RF_TILE - 1) / RF_TILE * RF_TILE);
-    const int numParts = 4096;
-    hipLaunchKernelGGL(peelTileKeysKernel, dim3(numCU * 4), dim3(256), 0, stream, slot, slotBase, n, padded, mode, keys, vals, uint32_t(numParts) << PMC_RF_BUCKET_BITS);
-    hipError_t e = launchPartition(keys, vals, sortedKeys, sortedVals, (unsigned long long)padded, numParts, temp, numCU, stream);
-    if (e != hipSuccess) return e;
-    const unsigned long long* start = static_cast<const unsigned long long*>(temp) + numParts;
-    hipLaunchKernelGGL(peelListKernel, dim3(numCU * 4), dim3(256), 0, stream, sortedVals, start, (uint32_t)numParts, list);
-    return hipGetLastError();
-}
-
 // end of a segment: statistics accumulator -> wifu arrays of the frames
 extern "C" hipError_t pmcLaunchStatMerge(int slot, int blocks, hipStream_t stream)
 {
