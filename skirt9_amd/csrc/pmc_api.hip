@@ -130,7 +130,7 @@ struct pmc_ctx
     unsigned long long rfCap[PMC_MAX_GROUPS]{};
     void* rfTemp[PMC_MAX_GROUPS]{};
     // sorted peel-off records (pmc_device.h PeelRec): per group the records in slot order and in tile order, the keys, the sort's counters
-    PeelRec* peelRec[PMC_MAX_GROUPS][2]{};
+    PeelRec* peelRec[PMC_MAX_GROUPS][2]{};  // ([1]: the sorted records; [0] unused)
     uint32_t* peelKeys[PMC_MAX_GROUPS]{};
     void* peelTemp[PMC_MAX_GROUPS]{};
     int peelCap[PMC_MAX_GROUPS]{};
@@ -1278,12 +1278,31 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             const int padded = (size[g] + 4095) / 4096 * 4096;
             if (ctx->peelCap[g] >= padded) continue;
             HIP_TRY(hipDeviceSynchronize());
+            // (a group that grows: the old buffers go first)
+            for (void* old : {static_cast<void*>(ctx->peelRec[g][1]), static_cast<void*>(ctx->peelKeys[g])})
+                if (old)
+                {
+                    hipFree(old);
+                    auto at = std::find(ctx->rfAllocations.begin(), ctx->rfAllocations.end(), old);
+                    if (at != ctx->rfAllocations.end()) ctx->rfAllocations.erase(at);
+                }
+            ctx->peelRec[g][1] = nullptr, ctx->peelKeys[g] = nullptr, ctx->peelCap[g] = 0;
+            // (no room for the records: the peel-off walks run from the task arrays, in slot order)
+            size_t freeBytes = 0, totalBytes = 0;
+            if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && size_t(padded) * (sizeof(PeelRec) + 4) + pmcPeelSortTempBytes() + (size_t(1) << 30) > freeBytes)
+            {
+                peelSortObs = -1;
+                break;
+            }
             int rc;
             if ((rc = ctx->allocate<PeelRec>(padded, &ctx->peelRec[g][1], false, &ctx->rfAllocations))) return rc;
             if ((rc = ctx->allocate<uint32_t>(padded, &ctx->peelKeys[g], false, &ctx->rfAllocations))) return rc;
-            uint8_t* t = nullptr;
-            if ((rc = ctx->allocate<uint8_t>(pmcPeelSortTempBytes(), &t, false, &ctx->rfAllocations))) return rc;
-            ctx->peelTemp[g] = t;
+            if (!ctx->peelTemp[g])
+            {
+                uint8_t* t = nullptr;
+                if ((rc = ctx->allocate<uint8_t>(pmcPeelSortTempBytes(), &t, false, &ctx->rfAllocations))) return rc;
+                ctx->peelTemp[g] = t;
+            }
             ctx->peelCap[g] = padded;
         }
     // ---- radiation field on an octree: the contributions of a generation go to a log per slot group (pmc_device.h RfLogArgs),
