@@ -40,8 +40,7 @@ extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const dou
 extern "C" int pmcPeelHasQueues(int wide, size_t ldsBytes);
 extern "C" const unsigned long long* pmcPeelSortedCount(void* temp);
 extern "C" size_t pmcPeelSortTempBytes();
-extern "C" hipError_t pmcLaunchPeelSort(int slot, int slotBase, int numSlots, int obs, const uint32_t* keys, PeelRec* sorted, int padded, void* temp, int numCU,
-                                        hipStream_t stream);
+extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlots, PeelSortArgs* ps, PeelRec* sorted, void* temp, int* groups, hipStream_t stream);
 extern "C" size_t pmcRfTempBytes(int numParts);
 extern "C" int pmcRfMaxParts();
 extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, const int* list, int listLen, int maxBlocks,
@@ -131,7 +130,6 @@ struct pmc_ctx
     void* rfTemp[PMC_MAX_GROUPS]{};
     // sorted peel-off records (pmc_device.h PeelRec): per group the records in slot order and in tile order, the keys, the sort's counters
     PeelRec* peelRec[PMC_MAX_GROUPS][2]{};  // ([1]: the sorted records; [0] unused)
-    uint32_t* peelKeys[PMC_MAX_GROUPS]{};
     void* peelTemp[PMC_MAX_GROUPS]{};
     int peelCap[PMC_MAX_GROUPS]{};
     size_t rfTempBytes{0};
@@ -1279,24 +1277,23 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             if (ctx->peelCap[g] >= padded) continue;
             HIP_TRY(hipDeviceSynchronize());
             // (a group that grows: the old buffers go first)
-            for (void* old : {static_cast<void*>(ctx->peelRec[g][1]), static_cast<void*>(ctx->peelKeys[g])})
+            for (void* old : {static_cast<void*>(ctx->peelRec[g][1])})
                 if (old)
                 {
                     hipFree(old);
                     auto at = std::find(ctx->rfAllocations.begin(), ctx->rfAllocations.end(), old);
                     if (at != ctx->rfAllocations.end()) ctx->rfAllocations.erase(at);
                 }
-            ctx->peelRec[g][1] = nullptr, ctx->peelKeys[g] = nullptr, ctx->peelCap[g] = 0;
+            ctx->peelRec[g][1] = nullptr, ctx->peelCap[g] = 0;
             // (no room for the records: the peel-off walks run from the task arrays, in slot order)
             size_t freeBytes = 0, totalBytes = 0;
-            if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && size_t(padded) * (sizeof(PeelRec) + 4) + pmcPeelSortTempBytes() + (size_t(1) << 30) > freeBytes)
+            if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && size_t(padded) * sizeof(PeelRec) + pmcPeelSortTempBytes() + (size_t(1) << 30) > freeBytes)
             {
                 peelSortObs = -1;
                 break;
             }
             int rc;
             if ((rc = ctx->allocate<PeelRec>(padded, &ctx->peelRec[g][1], false, &ctx->rfAllocations))) return rc;
-            if ((rc = ctx->allocate<uint32_t>(padded, &ctx->peelKeys[g], false, &ctx->rfAllocations))) return rc;
             if (!ctx->peelTemp[g])
             {
                 uint8_t* t = nullptr;
@@ -1483,13 +1480,14 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         int* const listOut = D.tasks.liveList + int64_t(listHalf[g]) * D.slots.num_slots + base[g];
         const bool sortNow = peelSortObs >= 0 && !buildList && !listIn;
         const double gdx = D.gx1 - D.gx0, gdy = D.gy1 - D.gy0, gdz = D.gz1 - D.gz0;
-        const PeelSortArgs sortArgs = {ctx->peelKeys[g], uint32_t(PMC_PEEL_TILES * PMC_PEEL_TILES) << PMC_RF_BUCKET_BITS, peelSortObs, (size[g] + 4095) / 4096 * 4096,
-                                       {0.5 * (D.gx0 + D.gx1), 0.5 * (D.gy0 + D.gy1), 0.5 * (D.gz0 + D.gz1)},
-                                       PMC_PEEL_TILES / std::sqrt(gdx * gdx + gdy * gdy + gdz * gdz)};
-        HIP_TRY(pmcLaunchCycleStart(ctx->slot, D.grid_kind, base[g], size[g], buildList ? PMC_CTR_LIST(g) : -1, listOut, listIn, listLen, cycleBlocks,
+        PeelSortArgs sortArgs = {nullptr, nullptr, nullptr, 0u, peelSortObs, 0, {0.5 * (D.gx0 + D.gx1), 0.5 * (D.gy0 + D.gy1), 0.5 * (D.gz0 + D.gz1)},
+                                 PMC_PEEL_TILES / std::sqrt(gdx * gdx + gdy * gdy + gdz * gdz)};
+        int sortGroups = 0;
+        // (sorted peel-off records: the sort's count pass over the slots as the transition / launch kernels left them; the cycle start kernel,
+        // with the same workgroups, is its scatter pass)
+        if (sortNow) HIP_TRY(pmcLaunchPeelSortCounts(ctx->slot, base[g], size[g], &sortArgs, ctx->peelRec[g][1], ctx->peelTemp[g], &sortGroups, sg));
+        HIP_TRY(pmcLaunchCycleStart(ctx->slot, D.grid_kind, base[g], size[g], buildList ? PMC_CTR_LIST(g) : -1, listOut, listIn, listLen, sortNow ? sortGroups : cycleBlocks,
                                     ctx->walkLds, sortNow ? &sortArgs : nullptr, sg));
-        if (sortNow)
-            HIP_TRY(pmcLaunchPeelSort(ctx->slot, base[g], size[g], peelSortObs, ctx->peelKeys[g], ctx->peelRec[g][1], (size[g] + 4095) / 4096 * 4096, ctx->peelTemp[g], ctx->numCU, sg));
         peelSorted[g] = sortNow;
         listBuilt[g] = buildList;
         HIP_TRY(hipEventRecord(ctx->evC[g], sg));

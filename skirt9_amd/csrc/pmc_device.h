@@ -348,11 +348,11 @@ struct RfLogArgs
     uint32_t padKey;         // key of the entries that fill up a wave's last chunk (beyond every table index)
 };
 // Octree, one observer: the peel-off walks of a generation as 64-byte records SORTED by the tile of the detector plane their start
-// position projects to.  The cycle start kernel writes the walks' start states to the task arrays as ever, and a sort key per slot of the
-// group; a counting sort on the tile (rfHistKernel / rfScanKernel / peelRecordScatterKernel) gathers the start states of the slots that
-// have a walk into records in tile order; the
-// peel-off kernel takes them in that order: its task loads are coalesced, and the walks in flight on the chip at any moment run
-// through one slab of the grid (parallel lines of sight from neighbouring tiles) -- the L2s hold it.
+// position projects to: a counting sort on the tile in which the cycle start kernel is the scatter pass.  peelSortCountKernel counts the
+// slots that will have a walk per tile (from the slot's mode word and position), workgroup by workgroup; the cycle start kernel -- same
+// workgroups, same slots -- writes every walk's start state straight to its place in tile order (one LDS atomic away).  The peel-off
+// kernel takes the records in that order: its task loads are coalesced, and the walks in flight on the chip at any moment run through
+// one slab of the grid (parallel lines of sight from neighbouring tiles) -- the L2s hold it.
 struct PeelRec
 {
     double rx, ry, rz;   // start of the walk (inside the grid)
@@ -363,14 +363,16 @@ struct PeelRec
     int32_t slot;        // where the optical depth goes (SlotArrays::ptau)
     uint32_t pad;
 };
-struct PeelSortArgs  // cycle start kernel; keys == nullptr: no sort
+struct PeelSortArgs  // sort-count kernel and cycle start kernel; out == nullptr: no sort, the walks' start states go to TaskArrays
 {
-    uint32_t* keys;      // [numSlots rounded up to whole sort tiles] tile << PMC_RF_BUCKET_BITS, or padKey (no walk)
-    uint32_t padKey;
-    int32_t obs;         // the observer (first instrument of its group)
-    int32_t padded;      // entries of `keys` (whole sort tiles): the ones beyond the group's slots are set to padKey
-    double centre[3];    // of the grid
-    double scale;        // PMC_PEEL_TILES / the grid's diagonal
+    PeelRec* out;                     // the group's records in tile order
+    uint32_t* matrix;                 // [workgroups][numParts]: entries of workgroup b's sort tiles per partition, then their prefix over the workgroups
+    const unsigned long long* start;  // [numParts + 1] first record of every partition (start[numParts] = number of records)
+    uint32_t numParts;                // PMC_PEEL_TILES^2
+    int32_t obs;                      // the observer (first instrument of its group)
+    int32_t ldsOffset;                // cycle start kernel: where its cursors live in LDS (behind the grid tables)
+    double centre[3];                 // of the grid
+    double scale;                     // PMC_PEEL_TILES / the grid's diagonal
 };
 struct PeelSortedArgs  // peel-off kernel; rec == nullptr: task records from TaskArrays
 {

@@ -308,7 +308,7 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
                {reinterpret_cast<const void*>(&traceRayKernel<GRID_CART>), walkMax},
                {reinterpret_cast<const void*>(&transitionKernel), transitionMax},
                {reinterpret_cast<const void*>(&launchKernel), transitionMax},
-               {reinterpret_cast<const void*>(&cycleStartKernel<GRID_TREE>), walkMax},
+               {reinterpret_cast<const void*>(&cycleStartKernel<GRID_TREE>), walkMax + 16 + size_t(PMC_PEEL_TILES) * PMC_PEEL_TILES * sizeof(uint32_t)},
                {reinterpret_cast<const void*>(&cycleStartKernel<GRID_CART>), walkMax},
                {reinterpret_cast<const void*>(&cycleStartKernel<GRID_VORO>), walkMax},
                {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, false, false>), walkMax},
@@ -386,9 +386,10 @@ extern "C" int pmcPeelHasQueues(int wide, size_t ldsBytes)
     static const bool first = getenv("PMC_PEEL_V1") != nullptr;
     return !first && (wide & 2) == 0 && ((ldsBytes + 15) & ~size_t(15)) + pmcPeelQueueBytes() <= size_t(160) * 1024;
 }
-// the peel-off walks of a group (keys in slot order, as many as whole sort tiles hold = `padded`; start states in the task arrays) -> records sorted by tile;
-// temp: pmcPeelSortTempBytes(); the number of sorted records is left at pmcPeelSortedCount(temp)
-constexpr int PEEL_SORT_GROUPS = 768;
+// sorted peel-off records (pmc_device.h PeelRec): the count pass of the sort over the slots of a group, behind its transition / launch kernels; the
+// cycle start kernel, launched with the SAME number of workgroups (returned through `groups`), is the scatter pass.  temp: pmcPeelSortTempBytes();
+// the number of sorted records is left at pmcPeelSortedCount(temp)
+constexpr int PEEL_SORT_GROUPS = 1024;
 constexpr int PEEL_SORT_PARTS = PMC_PEEL_TILES * PMC_PEEL_TILES;
 extern "C" size_t pmcPeelSortTempBytes()
 {
@@ -396,22 +397,22 @@ extern "C" size_t pmcPeelSortTempBytes()
     return (size_t(2) * PEEL_SORT_PARTS + 2) * sizeof(unsigned long long) + size_t(PEEL_SORT_GROUPS) * PEEL_SORT_PARTS * sizeof(uint32_t);
 }
 extern "C" const unsigned long long* pmcPeelSortedCount(void* temp) { return static_cast<const unsigned long long*>(temp) + 2 * PEEL_SORT_PARTS; }
-extern "C" hipError_t pmcLaunchPeelSort(int slot, int slotBase, int numSlots, int obs, const uint32_t* keys, PeelRec* sorted, int padded, void* temp, int numCU,
-                                        hipStream_t stream)
+extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlots, PeelSortArgs* ps, PeelRec* sorted, void* temp, int* groups, hipStream_t stream)
 {
-    const int numParts = PEEL_SORT_PARTS;
     unsigned long long* totals = static_cast<unsigned long long*>(temp);
-    unsigned long long* start = totals + numParts;
-    uint32_t* matrix = reinterpret_cast<uint32_t*>(totals + 2 * numParts + 2);
-    const unsigned long long tiles = (unsigned long long)padded / RF_TILE;
-    const unsigned groups = (unsigned)std::max<unsigned long long>(1ull, std::min<unsigned long long>(tiles, (unsigned long long)PEEL_SORT_GROUPS));
-    hipLaunchKernelGGL(peelSortCountKernel, dim3(groups), dim3(RF_SORT_BLOCK), 0, stream, keys, (unsigned long long)padded, (uint32_t)numParts, matrix);
-    hipLaunchKernelGGL(peelSortOffsetsKernel, dim3((numParts + 15) / 16), dim3(256), 0, stream, matrix, groups, (uint32_t)numParts, totals);
-    hipLaunchKernelGGL(rfScanKernel, dim3(1), dim3(1024), 0, stream, totals, start, (uint32_t)numParts);
-    hipLaunchKernelGGL(peelSortScatterKernel, dim3(groups), dim3(RF_SORT_BLOCK), 0, stream, slot, slotBase, obs, keys, (unsigned long long)padded, (uint32_t)numParts, matrix,
-                       start, sorted);
+    unsigned long long* start = totals + PEEL_SORT_PARTS;
+    ps->out = sorted;
+    ps->matrix = reinterpret_cast<uint32_t*>(totals + 2 * PEEL_SORT_PARTS + 2);
+    ps->start = start;
+    ps->numParts = PEEL_SORT_PARTS;
+    const int tiles = (numSlots + PEEL_SORT_TILE - 1) / PEEL_SORT_TILE;
+    *groups = std::max(1, std::min(tiles, PEEL_SORT_GROUPS));
+    hipLaunchKernelGGL(peelSortCountKernel, dim3(*groups), dim3(256), 0, stream, slot, slotBase, numSlots, *ps);
+    hipLaunchKernelGGL(peelSortOffsetsKernel, dim3((PEEL_SORT_PARTS + 15) / 16), dim3(256), 0, stream, ps->matrix, (uint32_t)*groups, (uint32_t)PEEL_SORT_PARTS, totals);
+    hipLaunchKernelGGL(rfScanKernel, dim3(1), dim3(1024), 0, stream, totals, start, (uint32_t)PEEL_SORT_PARTS);
     return hipGetLastError();
 }
+
 extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int grid, size_t ldsBytes,
                                     const PeelRec* sortedRec, const unsigned long long* sortedCount, hipStream_t stream)
 {
@@ -531,8 +532,15 @@ extern "C" hipError_t pmcLaunchLaunch(int slot, int slotBase, int numSlots, int 
 extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int listCounter, int* listOut, const int* listIn,
                                           int listLen, int maxBlocks, size_t ldsBytes, const PeelSortArgs* sort, hipStream_t stream)
 {
-    const PeelSortArgs none = {nullptr, 0u, -1, 0, {0., 0., 0.}, 0.};
-    const PeelSortArgs ps = sort ? *sort : none;
+    const PeelSortArgs none = {nullptr, nullptr, nullptr, 0u, -1, 0, {0., 0., 0.}, 0.};
+    PeelSortArgs ps = sort ? *sort : none;
+    if (ps.out)
+    {
+        // (the sort's cursors follow the grid tables in LDS)
+        ps.ldsOffset = int((ldsBytes + 15) & ~size_t(15));
+        ldsBytes = size_t(ps.ldsOffset) + size_t(PEEL_SORT_PARTS) * sizeof(uint32_t);
+    }
+    // (sorted peel-off records: as many workgroups as the sort's count pass had -- maxBlocks is that number then)
     const int grid = std::max(1, std::min(((listIn ? listLen : numSlots) + 255) / 256, maxBlocks));
     if (gridKind == PMC_GRID_OCTREE)
         hipLaunchKernelGGL(cycleStartKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter, listOut, listIn, listLen, ps);
