@@ -40,7 +40,8 @@ extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const dou
 extern "C" int pmcPeelHasQueues(int wide, size_t ldsBytes);
 extern "C" const unsigned long long* pmcPeelSortedCount(void* temp);
 extern "C" size_t pmcPeelSortTempBytes();
-extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlots, PeelSortArgs* ps, PeelRec* sorted, void* temp, int* groups, hipStream_t stream);
+extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlots, PeelSortArgs* ps, PeelRec* const* sorted, void* const* temp, int* groups,
+                                              hipStream_t stream);
 extern "C" size_t pmcRfTempBytes(int numParts);
 extern "C" int pmcRfMaxParts();
 extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, const int* list, int listLen, int maxBlocks,
@@ -129,8 +130,8 @@ struct pmc_ctx
     unsigned long long rfCap[PMC_MAX_GROUPS]{};
     void* rfTemp[PMC_MAX_GROUPS]{};
     // sorted peel-off records (pmc_device.h PeelRec): per group the records in slot order and in tile order, the keys, the sort's counters
-    PeelRec* peelRec[PMC_MAX_GROUPS][2]{};  // ([1]: the sorted records; [0] unused)
-    void* peelTemp[PMC_MAX_GROUPS]{};
+    PeelRec* peelRec[PMC_MAX_GROUPS][PMC_SORT_OBS]{};  // per group and sorted observer
+    void* peelTemp[PMC_MAX_GROUPS][PMC_SORT_OBS]{};
     int peelCap[PMC_MAX_GROUPS]{};
     size_t rfTempBytes{0};
 
@@ -1248,13 +1249,18 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     // sorted peel-off records (pmc_device.h PeelRec): an octree whose peel-off kernel runs with task queues, ONE observer (its records
     // are written by the cycle start kernel in slot order, sorted by detector tile, and read in tile order by the peel-off kernel)
     bool peelSorted[PMC_MAX_GROUPS] = {false, false, false, false};
-    int peelSortObs = -1;
+    int numSortObs = 0, sortObs[PMC_SORT_OBS] = {0, 0, 0, 0};
     if (D.grid_kind == PMC_GRID_OCTREE && getenv("PMC_NO_PEEL_SORT") == nullptr
         && pmcPeelHasQueues((ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), ctx->walkLds))
     {
         int observers = 0;
-        for (int i = 0; i < D.num_instruments; ++i) observers += D.inst[i].same_observer ? 0 : 1;
-        if (observers == 1) peelSortObs = 0;
+        for (int i = 0; i < D.num_instruments; ++i)
+            if (!D.inst[i].same_observer)
+            {
+                if (observers < PMC_SORT_OBS) sortObs[observers] = i;
+                ++observers;
+            }
+        if (observers <= PMC_SORT_OBS) numSortObs = observers;  // (more observers than that: all of them from the task arrays)
     }
     int listHalf[PMC_MAX_GROUPS] = {0, 0, 0, 0};  // the half of liveList that holds the group's current list
     int listTasksPerLane = 1;  // walks per lane that size the walk kernels' grids in a sparse generation
@@ -1270,38 +1276,42 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             haveWalk[g] = false;
         }
     }
-    if (peelSortObs >= 0)
-        for (int g = 0; g < G; ++g)
-        {
-            const int padded = (size[g] + 4095) / 4096 * 4096;
-            if (ctx->peelCap[g] >= padded) continue;
-            HIP_TRY(hipDeviceSynchronize());
-            // (a group that grows: the old buffers go first)
-            for (void* old : {static_cast<void*>(ctx->peelRec[g][1])})
-                if (old)
-                {
-                    hipFree(old);
-                    auto at = std::find(ctx->rfAllocations.begin(), ctx->rfAllocations.end(), old);
-                    if (at != ctx->rfAllocations.end()) ctx->rfAllocations.erase(at);
-                }
-            ctx->peelRec[g][1] = nullptr, ctx->peelCap[g] = 0;
-            // (no room for the records: the peel-off walks run from the task arrays, in slot order)
-            size_t freeBytes = 0, totalBytes = 0;
-            if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && size_t(padded) * sizeof(PeelRec) + pmcPeelSortTempBytes() + (size_t(1) << 30) > freeBytes)
+    for (int g = 0; g < G && numSortObs > 0; ++g)
+    {
+        const int padded = (size[g] + 4095) / 4096 * 4096;
+        if (ctx->peelCap[g] >= padded && ctx->peelRec[g][numSortObs - 1]) continue;
+        HIP_TRY(hipDeviceSynchronize());
+        // (a group that grows, or more observers than last time: the old buffers go first)
+        for (int k = 0; k < PMC_SORT_OBS; ++k)
+            if (ctx->peelRec[g][k])
             {
-                peelSortObs = -1;
-                break;
+                hipFree(ctx->peelRec[g][k]);
+                auto at = std::find(ctx->rfAllocations.begin(), ctx->rfAllocations.end(), static_cast<void*>(ctx->peelRec[g][k]));
+                if (at != ctx->rfAllocations.end()) ctx->rfAllocations.erase(at);
+                ctx->peelRec[g][k] = nullptr;
             }
-            int rc;
-            if ((rc = ctx->allocate<PeelRec>(padded, &ctx->peelRec[g][1], false, &ctx->rfAllocations))) return rc;
-            if (!ctx->peelTemp[g])
+        ctx->peelCap[g] = 0;
+        // (no room for the records: the peel-off walks run from the task arrays, in slot order)
+        size_t freeBytes = 0, totalBytes = 0;
+        if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess
+            && size_t(numSortObs) * (size_t(padded) * sizeof(PeelRec) + pmcPeelSortTempBytes()) + (size_t(1) << 30) > freeBytes)
+        {
+            numSortObs = 0;
+            break;
+        }
+        int rc;
+        for (int k = 0; k < numSortObs; ++k)
+        {
+            if ((rc = ctx->allocate<PeelRec>(padded, &ctx->peelRec[g][k], false, &ctx->rfAllocations))) return rc;
+            if (!ctx->peelTemp[g][k])
             {
                 uint8_t* t = nullptr;
                 if ((rc = ctx->allocate<uint8_t>(pmcPeelSortTempBytes(), &t, false, &ctx->rfAllocations))) return rc;
-                ctx->peelTemp[g] = t;
+                ctx->peelTemp[g][k] = t;
             }
-            ctx->peelCap[g] = padded;
         }
+        ctx->peelCap[g] = padded;
+    }
     // ---- radiation field on an octree: the contributions of a generation go to a log per slot group (pmc_device.h RfLogArgs),
     // which is partitioned by key range and summed after the generation.  128 entries per slot (config 2: 60 per propagation
     // walk on average); a wave that finds the log full falls back to atomic adds into the table.
@@ -1445,9 +1455,12 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 for (int i = 0; i < D.num_instruments; ++i)
                     if (!D.inst[i].same_observer)
                     {
-                        const bool sorted = peelSorted[g] && !list && i == peelSortObs;
+                        int k = -1;
+                        for (int q = 0; q < numSortObs; ++q)
+                            if (sortObs[q] == i) k = q;
+                        const bool sorted = peelSorted[g] && !list && k >= 0;
                         HIP_TRY(pmcLaunchPeel(ctx->slot, (ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), base[g], numTasks, sorted ? nullptr : list, PMC_CTR_TASK(g, 1 + i), i,
-                                              peelGrid, ctx->walkLds, sorted ? ctx->peelRec[g][1] : nullptr, sorted ? pmcPeelSortedCount(ctx->peelTemp[g]) : nullptr, sp));
+                                              peelGrid, ctx->walkLds, sorted ? ctx->peelRec[g][k] : nullptr, sorted ? pmcPeelSortedCount(ctx->peelTemp[g][k]) : nullptr, sp));
                     }
                 HIP_TRY(hipEventRecord(ctx->evJoin[g], sp));
                 RfLogArgs log = {ctx->rfKeys[g][0], ctx->rfVals[g][0], rfLogged ? ctx->rfCap[g] : 0ull, PMC_CTR_RFLOG(g), rfPadKey};
@@ -1478,14 +1491,19 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         const bool buildList = sparseLists && !initial && (listIn || ctx->pinned[g] < (unsigned long long)(size[g] / 2));
         if (listIn) listHalf[g] ^= 1;
         int* const listOut = D.tasks.liveList + int64_t(listHalf[g]) * D.slots.num_slots + base[g];
-        const bool sortNow = peelSortObs >= 0 && !buildList && !listIn;
+        const bool sortNow = numSortObs > 0 && !buildList && !listIn;
         const double gdx = D.gx1 - D.gx0, gdy = D.gy1 - D.gy0, gdz = D.gz1 - D.gz0;
-        PeelSortArgs sortArgs = {nullptr, nullptr, nullptr, 0u, peelSortObs, 0, {0.5 * (D.gx0 + D.gx1), 0.5 * (D.gy0 + D.gy1), 0.5 * (D.gz0 + D.gz1)},
-                                 PMC_PEEL_TILES / std::sqrt(gdx * gdx + gdy * gdy + gdz * gdz)};
+        PeelSortArgs sortArgs;
+        std::memset(&sortArgs, 0, sizeof(sortArgs));
+        sortArgs.numObs = numSortObs;
+        for (int i = 0; i < 16; ++i) sortArgs.sortIndex[i] = -1;
+        for (int k = 0; k < numSortObs; ++k) sortArgs.obs[k] = sortObs[k], sortArgs.sortIndex[sortObs[k]] = (int8_t)k;
+        sortArgs.centre[0] = 0.5 * (D.gx0 + D.gx1), sortArgs.centre[1] = 0.5 * (D.gy0 + D.gy1), sortArgs.centre[2] = 0.5 * (D.gz0 + D.gz1);
+        sortArgs.scale = PMC_PEEL_TILES / std::sqrt(gdx * gdx + gdy * gdy + gdz * gdz);
         int sortGroups = 0;
         // (sorted peel-off records: the sort's count pass over the slots as the transition / launch kernels left them; the cycle start kernel,
         // with the same workgroups, is its scatter pass)
-        if (sortNow) HIP_TRY(pmcLaunchPeelSortCounts(ctx->slot, base[g], size[g], &sortArgs, ctx->peelRec[g][1], ctx->peelTemp[g], &sortGroups, sg));
+        if (sortNow) HIP_TRY(pmcLaunchPeelSortCounts(ctx->slot, base[g], size[g], &sortArgs, ctx->peelRec[g], ctx->peelTemp[g], &sortGroups, sg));
         HIP_TRY(pmcLaunchCycleStart(ctx->slot, D.grid_kind, base[g], size[g], buildList ? PMC_CTR_LIST(g) : -1, listOut, listIn, listLen, sortNow ? sortGroups : cycleBlocks,
                                     ctx->walkLds, sortNow ? &sortArgs : nullptr, sg));
         peelSorted[g] = sortNow;

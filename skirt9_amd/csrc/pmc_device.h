@@ -347,7 +347,7 @@ struct RfLogArgs
     int32_t cursor;          // index of the log's cursor in DevScene::counters
     uint32_t padKey;         // key of the entries that fill up a wave's last chunk (beyond every table index)
 };
-// Octree, one observer: the peel-off walks of a generation as 64-byte records SORTED by the tile of the detector plane their start
+// Octree, up to PMC_SORT_OBS observers: the peel-off walks of a generation towards an observer as 64-byte records SORTED by the tile of the detector plane their start
 // position projects to: a counting sort on the tile in which the cycle start kernel is the scatter pass.  peelSortCountKernel counts the
 // slots that will have a walk per tile (from the slot's mode word and position), workgroup by workgroup; the cycle start kernel -- same
 // workgroups, same slots -- writes every walk's start state straight to its place in tile order (one LDS atomic away).  The peel-off
@@ -363,16 +363,19 @@ struct PeelRec
     int32_t slot;        // where the optical depth goes (SlotArrays::ptau)
     uint32_t pad;
 };
-struct PeelSortArgs  // sort-count kernel and cycle start kernel; out == nullptr: no sort, the walks' start states go to TaskArrays
+#define PMC_SORT_OBS 4  // observers whose peel-off walks are sorted (scenes with more observers: task arrays, slot order)
+struct PeelSortArgs  // sort-count kernel and cycle start kernel; numObs == 0: no sort, the walks' start states go to TaskArrays
 {
-    PeelRec* out;                     // the group's records in tile order
-    uint32_t* matrix;                 // [workgroups][numParts]: entries of workgroup b's sort tiles per partition, then their prefix over the workgroups
-    const unsigned long long* start;  // [numParts + 1] first record of every partition (start[numParts] = number of records)
-    uint32_t numParts;                // PMC_PEEL_TILES^2
-    int32_t obs;                      // the observer (first instrument of its group)
-    int32_t ldsOffset;                // cycle start kernel: where its cursors live in LDS (behind the grid tables)
-    double centre[3];                 // of the grid
-    double scale;                     // PMC_PEEL_TILES / the grid's diagonal
+    int32_t numObs;                             // sorted observers
+    int32_t obs[PMC_SORT_OBS];                  // their instruments (the first of each observer group)
+    int8_t sortIndex[16];                       // instrument -> index into the arrays below, or -1
+    PeelRec* out[PMC_SORT_OBS];                 // the group's records in tile order, per observer
+    uint32_t* matrix[PMC_SORT_OBS];             // [workgroups][numParts]: entries of workgroup b's sort tiles per partition, then their prefix over the workgroups
+    const unsigned long long* start[PMC_SORT_OBS];  // [numParts + 1] first record of every partition (start[numParts] = number of records)
+    uint32_t numParts;                          // PMC_PEEL_TILES^2
+    int32_t ldsOffset;                          // cycle start kernel: where its cursors live in LDS (behind the grid tables): numObs x numParts
+    double centre[3];                           // of the grid
+    double scale;                               // PMC_PEEL_TILES / the grid's diagonal
 };
 struct PeelSortedArgs  // peel-off kernel; rec == nullptr: task records from TaskArrays
 {

@@ -61,6 +61,7 @@
 #include "../../include/pmc_philox.h"
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <cstring>
 #include <float.h>
 #include <math.h>
 #include <algorithm>
@@ -308,7 +309,7 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
                {reinterpret_cast<const void*>(&traceRayKernel<GRID_CART>), walkMax},
                {reinterpret_cast<const void*>(&transitionKernel), transitionMax},
                {reinterpret_cast<const void*>(&launchKernel), transitionMax},
-               {reinterpret_cast<const void*>(&cycleStartKernel<GRID_TREE>), walkMax + 16 + size_t(PMC_PEEL_TILES) * PMC_PEEL_TILES * sizeof(uint32_t)},
+               {reinterpret_cast<const void*>(&cycleStartKernel<GRID_TREE>), walkMax + 16 + size_t(PMC_SORT_OBS) * PMC_PEEL_TILES * PMC_PEEL_TILES * sizeof(uint32_t)},
                {reinterpret_cast<const void*>(&cycleStartKernel<GRID_CART>), walkMax},
                {reinterpret_cast<const void*>(&cycleStartKernel<GRID_VORO>), walkMax},
                {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, false, false>), walkMax},
@@ -397,19 +398,27 @@ extern "C" size_t pmcPeelSortTempBytes()
     return (size_t(2) * PEEL_SORT_PARTS + 2) * sizeof(unsigned long long) + size_t(PEEL_SORT_GROUPS) * PEEL_SORT_PARTS * sizeof(uint32_t);
 }
 extern "C" const unsigned long long* pmcPeelSortedCount(void* temp) { return static_cast<const unsigned long long*>(temp) + 2 * PEEL_SORT_PARTS; }
-extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlots, PeelSortArgs* ps, PeelRec* sorted, void* temp, int* groups, hipStream_t stream)
+// (ps: numObs, obs, sortIndex, centre, scale set by the caller; sorted[k] / temp[k]: the records and counters of observer k)
+extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlots, PeelSortArgs* ps, PeelRec* const* sorted, void* const* temp, int* groups,
+                                              hipStream_t stream)
 {
-    unsigned long long* totals = static_cast<unsigned long long*>(temp);
-    unsigned long long* start = totals + PEEL_SORT_PARTS;
-    ps->out = sorted;
-    ps->matrix = reinterpret_cast<uint32_t*>(totals + 2 * PEEL_SORT_PARTS + 2);
-    ps->start = start;
     ps->numParts = PEEL_SORT_PARTS;
+    for (int k = 0; k < ps->numObs; ++k)
+    {
+        unsigned long long* totals = static_cast<unsigned long long*>(temp[k]);
+        ps->out[k] = sorted[k];
+        ps->matrix[k] = reinterpret_cast<uint32_t*>(totals + 2 * PEEL_SORT_PARTS + 2);
+        ps->start[k] = totals + PEEL_SORT_PARTS;
+    }
     const int tiles = (numSlots + PEEL_SORT_TILE - 1) / PEEL_SORT_TILE;
     *groups = std::max(1, std::min(tiles, PEEL_SORT_GROUPS));
     hipLaunchKernelGGL(peelSortCountKernel, dim3(*groups), dim3(256), 0, stream, slot, slotBase, numSlots, *ps);
-    hipLaunchKernelGGL(peelSortOffsetsKernel, dim3((PEEL_SORT_PARTS + 15) / 16), dim3(256), 0, stream, ps->matrix, (uint32_t)*groups, (uint32_t)PEEL_SORT_PARTS, totals);
-    hipLaunchKernelGGL(rfScanKernel, dim3(1), dim3(1024), 0, stream, totals, start, (uint32_t)PEEL_SORT_PARTS);
+    for (int k = 0; k < ps->numObs; ++k)
+    {
+        unsigned long long* totals = static_cast<unsigned long long*>(temp[k]);
+        hipLaunchKernelGGL(peelSortOffsetsKernel, dim3((PEEL_SORT_PARTS + 15) / 16), dim3(256), 0, stream, ps->matrix[k], (uint32_t)*groups, (uint32_t)PEEL_SORT_PARTS, totals);
+        hipLaunchKernelGGL(rfScanKernel, dim3(1), dim3(1024), 0, stream, totals, totals + PEEL_SORT_PARTS, (uint32_t)PEEL_SORT_PARTS);
+    }
     return hipGetLastError();
 }
 
@@ -532,15 +541,15 @@ extern "C" hipError_t pmcLaunchLaunch(int slot, int slotBase, int numSlots, int 
 extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int listCounter, int* listOut, const int* listIn,
                                           int listLen, int maxBlocks, size_t ldsBytes, const PeelSortArgs* sort, hipStream_t stream)
 {
-    const PeelSortArgs none = {nullptr, nullptr, nullptr, 0u, -1, 0, {0., 0., 0.}, 0.};
-    PeelSortArgs ps = sort ? *sort : none;
-    if (ps.out)
+    PeelSortArgs ps;
+    std::memset(&ps, 0, sizeof(ps));
+    if (sort) ps = *sort;
+    if (ps.numObs > 0)
     {
-        // (the sort's cursors follow the grid tables in LDS)
+        // (the sorts' cursors follow the grid tables in LDS; as many workgroups as the sort's count pass had: maxBlocks is that number then)
         ps.ldsOffset = int((ldsBytes + 15) & ~size_t(15));
-        ldsBytes = size_t(ps.ldsOffset) + size_t(PEEL_SORT_PARTS) * sizeof(uint32_t);
+        ldsBytes = size_t(ps.ldsOffset) + size_t(ps.numObs) * PEEL_SORT_PARTS * sizeof(uint32_t);
     }
-    // (sorted peel-off records: as many workgroups as the sort's count pass had -- maxBlocks is that number then)
     const int grid = std::max(1, std::min(((listIn ? listLen : numSlots) + 255) / 256, maxBlocks));
     if (gridKind == PMC_GRID_OCTREE)
         hipLaunchKernelGGL(cycleStartKernel<GRID_TREE>, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, listCounter, listOut, listIn, listLen, ps);

@@ -287,7 +287,7 @@ def test_full_size_radiation_field_log_partition(tmp_path, monkeypatch):
 
 
 def test_full_size_sorted_peel_records_change_nothing(full, monkeypatch):
-    """The peel-off walks of a generation run from records sorted by detector tile (pmc_device.h PeelRec; one observer, octree); PMC_NO_PEEL_SORT=1
+    """The peel-off walks of a generation run from records sorted by detector tile (pmc_device.h PeelRec; up to four observers, octree); PMC_NO_PEEL_SORT=1
     runs them from the task arrays in slot order as in rounds 1-3.  Same histories, same walks: the counted work is identical, the integer
     counts are identical, the sums agree to summation order."""
     from skirt9_amd.engine import Engine
