@@ -308,3 +308,37 @@ def test_full_size_sorted_peel_records_change_nothing(full, monkeypatch):
     assert np.array_equal(a[w0], b[w0])
     assert abs(a.sum() - b.sum()) <= 1e-11 * np.abs(b).sum()
     assert (np.abs(a - b) > 1e-9 * np.abs(b) + 1e-15 * np.abs(b).max()).sum() == 0
+
+
+def test_full_size_sorted_peel_records_three_observers(tmp_path, monkeypatch):
+    """The same with three observers (three FullInstruments at 0 / 60 / 90 degrees: three sets of sorted records, three peel-off kernels per
+    generation) against the slot-order form, and both against the oracle on 2e4 histories."""
+    import re
+    from skirt9_amd.engine import Engine
+    from test_gpu_parity import _compare_frames
+    text = open(ski("cfg2.ski")).read()
+    ins = re.search(r"<FullInstrument [^>]*/>", text).group(0)
+    a = ins.replace('instrumentName="i0"', 'instrumentName="i1"').replace('inclination="60 deg"', 'inclination="0 deg"')
+    b = ins.replace('instrumentName="i0"', 'instrumentName="i2"').replace('inclination="60 deg"', 'inclination="90 deg"').replace('azimuth="30 deg"', 'azimuth="0 deg"')
+    assert a != ins and b != ins
+    path = tmp_path / "cfg2three.ski"
+    path.write_text(text.replace(ins, ins + a + b))
+    n = 300000
+    sim = Simulation(str(path), num_packets=n).setup()
+    eng = Engine(sim.scene, 0)
+    eng.run_primary(0, n, 5)
+    a_frames, ca = eng.download(), eng.counters()
+    eng.clear()
+    eng.run_primary(0, 20000, 6)
+    small = eng.download()
+    eng.close()
+    ref, _ = O.run_primary(sim, 0, 20000, O.RNG_PHILOX, seed=6)
+    _compare_frames(sim, small, ref, 20000)
+    monkeypatch.setenv("PMC_NO_PEEL_SORT", "1")
+    plain = Engine(sim.scene, 0)
+    plain.run_primary(0, n, 5)
+    b_frames, cb = plain.download(), plain.counters()
+    plain.close()
+    assert ca["cell_visits"] == cb["cell_visits"] and ca["scatterings"] == cb["scatterings"]
+    assert abs(a_frames.sum() - b_frames.sum()) <= 1e-11 * np.abs(b_frames).sum()
+    assert (np.abs(a_frames - b_frames) > 1e-9 * np.abs(b_frames) + 1e-15 * np.abs(b_frames).max()).sum() == 0
