@@ -30,7 +30,7 @@ extern "C" hipError_t pmcLaunchStatMerge(int slot, int blocks, hipStream_t strea
 extern "C" int pmcPeelBlock(void);
 extern "C" int pmcPropBlock(void);
 extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int taskBase, int numTaskRecords, int taskCounter, uint64_t seed, int grid,
-                                    int block, size_t ldsBytes, hipStream_t stream);
+                                    int block, size_t ldsBytes, const WalkStreamArgs* tasks, hipStream_t stream);
 extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int grid, size_t ldsBytes,
                                     const PeelRec* sortedRec, const unsigned long long* sortedCount, hipStream_t stream);
 extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, const int* list, int cursor, uint64_t seed, int grid,
@@ -40,8 +40,8 @@ extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const dou
 extern "C" int pmcPeelHasQueues(int wide, size_t ldsBytes);
 extern "C" const unsigned long long* pmcPeelSortedCount(void* temp);
 extern "C" size_t pmcPeelSortTempBytes();
-extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlots, PeelSortArgs* ps, PeelRec* const* sorted, void* const* temp, int* groups,
-                                              hipStream_t stream);
+extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlots, PeelSortArgs* ps, PeelRec* const* sorted, int32_t* const* lists, void* const* temp,
+                                              int* groups, hipStream_t stream);
 extern "C" size_t pmcRfTempBytes(int numParts);
 extern "C" int pmcRfMaxParts();
 extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, const int* list, int listLen, int maxBlocks,
@@ -130,7 +130,8 @@ struct pmc_ctx
     unsigned long long rfCap[PMC_MAX_GROUPS]{};
     void* rfTemp[PMC_MAX_GROUPS]{};
     // sorted peel-off records (pmc_device.h PeelRec): per group the records in slot order and in tile order, the keys, the sort's counters
-    PeelRec* peelRec[PMC_MAX_GROUPS][PMC_SORT_OBS]{};  // per group and sorted observer
+    PeelRec* peelRec[PMC_MAX_GROUPS][PMC_SORT_OBS]{};  // per group and sorted observer (octree)
+    int32_t* peelList[PMC_MAX_GROUPS][PMC_SORT_OBS]{};  // (Cartesian, Voronoi) the slots in tile order instead
     void* peelTemp[PMC_MAX_GROUPS][PMC_SORT_OBS]{};
     int peelCap[PMC_MAX_GROUPS]{};
     size_t rfTempBytes{0};
@@ -1250,8 +1251,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     // are written by the cycle start kernel in slot order, sorted by detector tile, and read in tile order by the peel-off kernel)
     bool peelSorted[PMC_MAX_GROUPS] = {false, false, false, false};
     int numSortObs = 0, sortObs[PMC_SORT_OBS] = {0, 0, 0, 0};
-    if (D.grid_kind == PMC_GRID_OCTREE && getenv("PMC_NO_PEEL_SORT") == nullptr
-        && pmcPeelHasQueues((ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), ctx->walkLds))
+    const bool octree = D.grid_kind == PMC_GRID_OCTREE;
+    if (getenv("PMC_NO_PEEL_SORT") == nullptr && (!octree || pmcPeelHasQueues((ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), ctx->walkLds)))
     {
         int observers = 0;
         for (int i = 0; i < D.num_instruments; ++i)
@@ -1279,17 +1280,18 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     for (int g = 0; g < G && numSortObs > 0; ++g)
     {
         const int padded = (size[g] + 4095) / 4096 * 4096;
-        if (ctx->peelCap[g] >= padded && ctx->peelRec[g][numSortObs - 1]) continue;
+        if (ctx->peelCap[g] >= padded && (octree ? (void*)ctx->peelRec[g][numSortObs - 1] : (void*)ctx->peelList[g][numSortObs - 1])) continue;
         HIP_TRY(hipDeviceSynchronize());
         // (a group that grows, or more observers than last time: the old buffers go first)
         for (int k = 0; k < PMC_SORT_OBS; ++k)
-            if (ctx->peelRec[g][k])
-            {
-                hipFree(ctx->peelRec[g][k]);
-                auto at = std::find(ctx->rfAllocations.begin(), ctx->rfAllocations.end(), static_cast<void*>(ctx->peelRec[g][k]));
-                if (at != ctx->rfAllocations.end()) ctx->rfAllocations.erase(at);
-                ctx->peelRec[g][k] = nullptr;
-            }
+            for (void* old : {static_cast<void*>(ctx->peelRec[g][k]), static_cast<void*>(ctx->peelList[g][k])})
+                if (old)
+                {
+                    hipFree(old);
+                    auto at = std::find(ctx->rfAllocations.begin(), ctx->rfAllocations.end(), old);
+                    if (at != ctx->rfAllocations.end()) ctx->rfAllocations.erase(at);
+                }
+        for (int k = 0; k < PMC_SORT_OBS; ++k) ctx->peelRec[g][k] = nullptr, ctx->peelList[g][k] = nullptr;
         ctx->peelCap[g] = 0;
         // (no room for the records: the peel-off walks run from the task arrays, in slot order)
         size_t freeBytes = 0, totalBytes = 0;
@@ -1302,7 +1304,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         int rc;
         for (int k = 0; k < numSortObs; ++k)
         {
-            if ((rc = ctx->allocate<PeelRec>(padded, &ctx->peelRec[g][k], false, &ctx->rfAllocations))) return rc;
+            if (octree && (rc = ctx->allocate<PeelRec>(padded, &ctx->peelRec[g][k], false, &ctx->rfAllocations))) return rc;
+            if (!octree && (rc = ctx->allocate<int32_t>(padded, &ctx->peelList[g][k], false, &ctx->rfAllocations))) return rc;
             if (!ctx->peelTemp[g][k])
             {
                 uint8_t* t = nullptr;
@@ -1470,8 +1473,20 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 HIP_TRY(hipStreamWaitEvent(sg, ctx->evJoin[g], 0));
             }
             else
+            {
+                // (sorted observers: one stream of single walks -- the propagation walks in slot order, then every observer's peel-off walks in the
+                // order of the detector tile they start behind)
+                WalkStreamArgs tasks;
+                std::memset(&tasks, 0, sizeof(tasks));
+                if (peelSorted[g])
+                {
+                    tasks.numLists = numSortObs;
+                    for (int k = 0; k < numSortObs; ++k)
+                        tasks.rec[k] = 1 + sortObs[k], tasks.list[k] = ctx->peelList[g][k], tasks.count[k] = pmcPeelSortedCount(ctx->peelTemp[g][k]);
+                }
                 HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0) | (D.num_media > 1 ? 4 : 0), base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->block,
-                                      ctx->walkLds, sg));
+                                      ctx->walkLds, peelSorted[g] ? &tasks : nullptr, sg));
+            }
             haveWalk[g] = true;
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_LIVE(g), 0, sizeof(unsigned long long), sg));
@@ -1503,7 +1518,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         int sortGroups = 0;
         // (sorted peel-off records: the sort's count pass over the slots as the transition / launch kernels left them; the cycle start kernel,
         // with the same workgroups, is its scatter pass)
-        if (sortNow) HIP_TRY(pmcLaunchPeelSortCounts(ctx->slot, base[g], size[g], &sortArgs, ctx->peelRec[g], ctx->peelTemp[g], &sortGroups, sg));
+        if (sortNow)
+            HIP_TRY(pmcLaunchPeelSortCounts(ctx->slot, base[g], size[g], &sortArgs, octree ? ctx->peelRec[g] : nullptr, octree ? nullptr : ctx->peelList[g], ctx->peelTemp[g], &sortGroups, sg));
         HIP_TRY(pmcLaunchCycleStart(ctx->slot, D.grid_kind, base[g], size[g], buildList ? PMC_CTR_LIST(g) : -1, listOut, listIn, listLen, sortNow ? sortGroups : cycleBlocks,
                                     ctx->walkLds, sortNow ? &sortArgs : nullptr, sg));
         peelSorted[g] = sortNow;

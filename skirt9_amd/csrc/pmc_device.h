@@ -369,13 +369,24 @@ struct PeelSortArgs  // sort-count kernel and cycle start kernel; numObs == 0: n
     int32_t numObs;                             // sorted observers
     int32_t obs[PMC_SORT_OBS];                  // their instruments (the first of each observer group)
     int8_t sortIndex[16];                       // instrument -> index into the arrays below, or -1
-    PeelRec* out[PMC_SORT_OBS];                 // the group's records in tile order, per observer
+    PeelRec* out[PMC_SORT_OBS];                 // (octree) the group's records in tile order, per observer
+    int32_t* listOut[PMC_SORT_OBS];             // (Cartesian, Voronoi) the group's slots in tile order, per observer: the walks' start states stay in TaskArrays
     uint32_t* matrix[PMC_SORT_OBS];             // [workgroups][numParts]: entries of workgroup b's sort tiles per partition, then their prefix over the workgroups
     const unsigned long long* start[PMC_SORT_OBS];  // [numParts + 1] first record of every partition (start[numParts] = number of records)
     uint32_t numParts;                          // PMC_PEEL_TILES^2
     int32_t ldsOffset;                          // cycle start kernel: where its cursors live in LDS (behind the grid tables): numObs x numParts
     double centre[3];                           // of the grid
     double scale;                               // PMC_PEEL_TILES / the grid's diagonal
+};
+// Cartesian / Voronoi walk kernel: the walks of a generation as ONE stream of tasks -- the propagation walks of the group's slots in slot
+// order (record 0), then for every sorted observer its peel-off walks in tile order (lists of slots written by the cycle start kernel).
+// numLists == 0: a task is a slot with all its walks, in slot order (scenes with more than PMC_SORT_OBS observers)
+struct WalkStreamArgs
+{
+    int32_t numLists;
+    int32_t rec[PMC_SORT_OBS];                      // task record of the walks of list k (1 + instrument)
+    const int32_t* list[PMC_SORT_OBS];
+    const unsigned long long* count[PMC_SORT_OBS];  // entries of list k (device memory)
 };
 struct PeelSortedArgs  // peel-off kernel; rec == nullptr: task records from TaskArrays
 {

@@ -310,8 +310,8 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
                {reinterpret_cast<const void*>(&transitionKernel), transitionMax},
                {reinterpret_cast<const void*>(&launchKernel), transitionMax},
                {reinterpret_cast<const void*>(&cycleStartKernel<GRID_TREE>), walkMax + 16 + size_t(PMC_SORT_OBS) * PMC_PEEL_TILES * PMC_PEEL_TILES * sizeof(uint32_t)},
-               {reinterpret_cast<const void*>(&cycleStartKernel<GRID_CART>), walkMax},
-               {reinterpret_cast<const void*>(&cycleStartKernel<GRID_VORO>), walkMax},
+               {reinterpret_cast<const void*>(&cycleStartKernel<GRID_CART>), walkMax + 16 + size_t(PMC_SORT_OBS) * PMC_PEEL_TILES * PMC_PEEL_TILES * sizeof(uint32_t)},
+               {reinterpret_cast<const void*>(&cycleStartKernel<GRID_VORO>), walkMax + 16 + size_t(PMC_SORT_OBS) * PMC_PEEL_TILES * PMC_PEEL_TILES * sizeof(uint32_t)},
                {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, false, false>), walkMax},
                {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, true, false, false>), walkMax},
                {reinterpret_cast<const void*>(&walkKernel<GRID_VORO, false, true, false>), walkMax},
@@ -362,13 +362,16 @@ extern "C" int pmcPropBlock(void)
 // walks of the task records [taskBase, taskBase + numTaskRecords) of one slot group on a Cartesian or Voronoi grid;
 // taskCounter = index of the group's (zeroed) cursor
 extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int taskBase, int numTaskRecords, int taskCounter,
-                                    uint64_t seed, int grid, int block, size_t ldsBytes, hipStream_t stream)
+                                    uint64_t seed, int grid, int block, size_t ldsBytes, const WalkStreamArgs* tasks, hipStream_t stream)
 {
+    WalkStreamArgs ws;
+    std::memset(&ws, 0, sizeof(ws));
+    if (tasks) ws = *tasks;
     // (the radiation-field and the explicit-absorption flavours are separate instantiations: the plain photon loop pays nothing for
     // them; storeRf: bit 0 = the radiation field is stored, bit 1 = explicit absorption)
     // (bit 2 = several medium components)
     const int flavour = storeRf & 7;
-    typedef void (*Kernel)(int, int, int, int, uint64_t);
+    typedef void (*Kernel)(int, int, int, int, uint64_t, WalkStreamArgs);
     static const Kernel cart[8] = {walkKernel<GRID_CART, false, false, false>, walkKernel<GRID_CART, true, false, false>, walkKernel<GRID_CART, false, true, false>,
                                    walkKernel<GRID_CART, true, true, false>,   walkKernel<GRID_CART, false, false, true>, walkKernel<GRID_CART, true, false, true>,
                                    walkKernel<GRID_CART, false, true, true>,   walkKernel<GRID_CART, true, true, true>};
@@ -376,7 +379,7 @@ extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int tas
                                    walkKernel<GRID_VORO, true, true, false>,   walkKernel<GRID_VORO, false, false, true>, walkKernel<GRID_VORO, true, false, true>,
                                    walkKernel<GRID_VORO, false, true, true>,   walkKernel<GRID_VORO, true, true, true>};
     const Kernel kernel = gridKind == PMC_GRID_VORONOI ? voro[flavour] : cart[flavour];
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter, seed);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter, seed, ws);
     return hipGetLastError();
 }
 
@@ -399,14 +402,15 @@ extern "C" size_t pmcPeelSortTempBytes()
 }
 extern "C" const unsigned long long* pmcPeelSortedCount(void* temp) { return static_cast<const unsigned long long*>(temp) + 2 * PEEL_SORT_PARTS; }
 // (ps: numObs, obs, sortIndex, centre, scale set by the caller; sorted[k] / temp[k]: the records and counters of observer k)
-extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlots, PeelSortArgs* ps, PeelRec* const* sorted, void* const* temp, int* groups,
-                                              hipStream_t stream)
+extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlots, PeelSortArgs* ps, PeelRec* const* sorted, int32_t* const* lists, void* const* temp,
+                                              int* groups, hipStream_t stream)
 {
     ps->numParts = PEEL_SORT_PARTS;
     for (int k = 0; k < ps->numObs; ++k)
     {
         unsigned long long* totals = static_cast<unsigned long long*>(temp[k]);
-        ps->out[k] = sorted[k];
+        ps->out[k] = sorted ? sorted[k] : nullptr;
+        ps->listOut[k] = lists ? lists[k] : nullptr;
         ps->matrix[k] = reinterpret_cast<uint32_t*>(totals + 2 * PEEL_SORT_PARTS + 2);
         ps->start[k] = totals + PEEL_SORT_PARTS;
     }
