@@ -32,7 +32,7 @@ extern "C" int pmcPropBlock(void);
 extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int taskBase, int numTaskRecords, int taskCounter, uint64_t seed, int grid,
                                     int block, size_t ldsBytes, const WalkStreamArgs* tasks, hipStream_t stream);
 extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int grid, size_t ldsBytes,
-                                    const PeelRec* sortedRec, const unsigned long long* sortedCount, hipStream_t stream);
+                                    const PeelRec* sortedRec, const unsigned long long* sortedCount, unsigned long long* xcdCursor, hipStream_t stream);
 extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, const int* list, int cursor, uint64_t seed, int grid,
                                     size_t ldsBytes, const RfLogArgs* rfLog, hipStream_t stream);
 extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n,
@@ -133,6 +133,7 @@ struct pmc_ctx
     PeelRec* peelRec[PMC_MAX_GROUPS][PMC_SORT_OBS]{};  // per group and sorted observer (octree)
     int32_t* peelList[PMC_MAX_GROUPS][PMC_SORT_OBS]{};  // (Cartesian, Voronoi) the slots in tile order instead
     void* peelTemp[PMC_MAX_GROUPS][PMC_SORT_OBS]{};
+    unsigned long long* xcdCursors{nullptr};  // [PMC_MAX_GROUPS][PMC_SORT_OBS][8] the peel-off kernels' cursors over the eighths of the sorted records
     int peelCap[PMC_MAX_GROUPS]{};
     size_t rfTempBytes{0};
 
@@ -1251,6 +1252,12 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     // are written by the cycle start kernel in slot order, sorted by detector tile, and read in tile order by the peel-off kernel)
     bool peelSorted[PMC_MAX_GROUPS] = {false, false, false, false};
     int numSortObs = 0, sortObs[PMC_SORT_OBS] = {0, 0, 0, 0};
+    const bool xcdAffinity = getenv("PMC_NO_XCD_AFFINITY") == nullptr;
+    if (!ctx->xcdCursors)
+    {
+        int rc;
+        if ((rc = ctx->allocate<unsigned long long>(size_t(PMC_MAX_GROUPS) * PMC_SORT_OBS * 8, &ctx->xcdCursors, true, &ctx->rfAllocations))) return rc;
+    }
     const bool octree = D.grid_kind == PMC_GRID_OCTREE;
     if (getenv("PMC_NO_PEEL_SORT") == nullptr && (!octree || pmcPeelHasQueues((ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), ctx->walkLds)))
     {
@@ -1442,6 +1449,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             if (int rc = rfFlush(g, ctx->pinned[PMC_MAX_GROUPS + g])) return rc;
             ctx->pinned[PMC_MAX_GROUPS + g] = 0;
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(g, 0), 0, PMC_CTR_TASKS_PER_GROUP * sizeof(unsigned long long), sg));  // task cursors
+            if (ctx->xcdCursors) HIP_TRY(hipMemsetAsync(ctx->xcdCursors + size_t(g) * PMC_SORT_OBS * 8, 0, PMC_SORT_OBS * 8 * sizeof(unsigned long long), sg));
             HIP_TRY(hipEventRecord(ctx->evA[g], sg));
             if (D.grid_kind == PMC_GRID_OCTREE)
             {
@@ -1463,7 +1471,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                             if (sortObs[q] == i) k = q;
                         const bool sorted = peelSorted[g] && !list && k >= 0;
                         HIP_TRY(pmcLaunchPeel(ctx->slot, (ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), base[g], numTasks, sorted ? nullptr : list, PMC_CTR_TASK(g, 1 + i), i,
-                                              peelGrid, ctx->walkLds, sorted ? ctx->peelRec[g][k] : nullptr, sorted ? pmcPeelSortedCount(ctx->peelTemp[g][k]) : nullptr, sp));
+                                              peelGrid, ctx->walkLds, sorted ? ctx->peelRec[g][k] : nullptr, sorted ? pmcPeelSortedCount(ctx->peelTemp[g][k]) : nullptr,
+                                              sorted && xcdAffinity ? ctx->xcdCursors + (size_t(g) * PMC_SORT_OBS + k) * 8 : nullptr, sp));
                     }
                 HIP_TRY(hipEventRecord(ctx->evJoin[g], sp));
                 RfLogArgs log = {ctx->rfKeys[g][0], ctx->rfVals[g][0], rfLogged ? ctx->rfCap[g] : 0ull, PMC_CTR_RFLOG(g), rfPadKey};
@@ -1483,6 +1492,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                     tasks.numLists = numSortObs;
                     for (int k = 0; k < numSortObs; ++k)
                         tasks.rec[k] = 1 + sortObs[k], tasks.list[k] = ctx->peelList[g][k], tasks.count[k] = pmcPeelSortedCount(ctx->peelTemp[g][k]);
+                    tasks.xcdCursor = xcdAffinity ? ctx->xcdCursors + size_t(g) * PMC_SORT_OBS * 8 : nullptr;
                 }
                 HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0) | (D.num_media > 1 ? 4 : 0), base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->block,
                                       ctx->walkLds, peelSorted[g] ? &tasks : nullptr, sg));

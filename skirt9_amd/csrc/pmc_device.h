@@ -387,11 +387,15 @@ struct WalkStreamArgs
     int32_t rec[PMC_SORT_OBS];                      // task record of the walks of list k (1 + instrument)
     const int32_t* list[PMC_SORT_OBS];
     const unsigned long long* count[PMC_SORT_OBS];  // entries of list k (device memory)
+    unsigned long long* xcdCursor;                  // [8] (or null) one cursor per eighth of the stream: an XCD's workgroups take their own eighth first
 };
 struct PeelSortedArgs  // peel-off kernel; rec == nullptr: task records from TaskArrays
 {
     const PeelRec* rec;
     const unsigned long long* count;  // number of sorted records (device memory)
+    unsigned long long* xcdCursor;    // [8] one cursor per eighth of the records: the workgroups of an XCD take the walks of their own eighth
+                                      // of the tile order first (then the others'), so that the L2 of an XCD sees an eighth of the slab the
+                                      // walks in flight run through
 };
 #ifndef PMC_PEEL_TILES
 #define PMC_PEEL_TILES 32  // tiles per axis of the detector plane (PMC_PEEL_TILES^2 sort partitions)

@@ -427,7 +427,7 @@ extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlo
 }
 
 extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int grid, size_t ldsBytes,
-                                    const PeelRec* sortedRec, const unsigned long long* sortedCount, hipStream_t stream)
+                                    const PeelRec* sortedRec, const unsigned long long* sortedCount, unsigned long long* xcdCursor, hipStream_t stream)
 {
     static const bool first = getenv("PMC_PEEL_V1") != nullptr;  // (tuning aid: the form with service rounds)
     // (`wide` bit 1: several medium components -- the form with service rounds)
@@ -444,7 +444,7 @@ extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlo
         // (the waves' task queues follow the grid tables in LDS)
         auto kernel = wide ? walkPeelKernel2<true> : walkPeelKernel2<false>;
         const size_t queueOffset = (ldsBytes + 15) & ~size_t(15);
-        const PeelSortedArgs sorted = {sortedRec, sortedCount};
+        const PeelSortedArgs sorted = {sortedRec, sortedCount, xcdCursor};
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PEEL_BLOCK), queueOffset + pmcPeelQueueBytes(), stream, slot, slotBase, numSlots, cursor, obs,
                            (int)queueOffset, list, sorted);
     }
