@@ -1239,6 +1239,14 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     // latency-bound transition kernel overlap with the walk kernel of another group.
     int G = ctx->numGroups;
     if (numSlots < G * 65536) G = 1;
+    {
+        // (Voronoi: the walk kernel is nine tenths of the step, and its walks run as ONE stream in tile order: a second and third group would
+        // put two more streams in flight next to it and triple the cells the L2s have to hold -- 5e7 packets: 2.18 / 2.13 / 2.04e7 packets/s
+        // with one / two / three groups)
+        int observers = 0;
+        for (int i = 0; i < D.num_instruments; ++i) observers += D.inst[i].same_observer ? 0 : 1;
+        if (D.grid_kind == PMC_GRID_VORONOI && observers <= PMC_SORT_OBS && getenv("PMC_NUM_GROUPS") == nullptr && getenv("PMC_NO_PEEL_SORT") == nullptr) G = 1;
+    }
     int base[PMC_MAX_GROUPS], size[PMC_MAX_GROUPS];
     bool active[PMC_MAX_GROUPS], haveWalk[PMC_MAX_GROUPS];
     // sparse generations (the end of a segment, when no history is left to launch): the cycle start kernel compacts the live
