@@ -793,7 +793,8 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
                                     const bool negative = ((sgn >> (wall >> 1)) & 1) != 0;
                                     skip = (wall & 1) ? negative : !negative;
                                 }
-                                if (skip) cull[size_t(m) * PMC_VORO_CONES + (sgn * 6 + p) * (PMC_VORO_CONES / 48) + c] |= 1u << j;
+                                // (cone-major: the masks of one cone are consecutive -- the walks towards an observer all use one cone)
+                                if (skip) cull[size_t((sgn * 6 + p) * (PMC_VORO_CONES / 48) + c) * size_t(ncell) + size_t(m)] |= 1u << j;
                             }
                         }
                 }

@@ -257,7 +257,8 @@ struct DevScene
                                   // words per neighbour from consecutive addresses instead of index -> site gathers
     const double* vhead;          // [num_cells][8]: per cell ONE 64-byte record {site x, y, z, number density, list start | list end
                                   // (two int32 in one double), 3 unused}: what a walk reads of the cell it enters, in one sector
-    const uint32_t* vcull;        // [num_cells][PMC_VORO_CONES]: per cell and direction cone (sign pattern of k x order of |k_x|, |k_y|,
+    const uint32_t* vcull;        // [PMC_VORO_CONES][num_cells] (cone-major: a walk keeps its cone, and all peel-off walks towards an observer share
+                                  // one: 4 bytes per cell of a 400 KB slice instead of one line per visit): per cell and direction cone (sign pattern of k x order of |k_x|, |k_y|,
                                   // |k_z|) bit j set: the j-th neighbour of the list (j < 32) lies behind every direction of the
                                   // cone (n . k < 0 with a margin far above rounding), or is a domain wall the cone moves away
                                   // from: the reference skips it (ndotk > 0 fails), and the walk does not even read it
