@@ -735,6 +735,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
             if ((rc = ctx->upload(head.data(), head.size(), &D.vhead))) return bail(rc);
         }
         D.vcull = nullptr;
+        for (int i = 0; i < 16; ++i) D.vobs_of_inst[i] = -1;
         if (!getenv("PMC_VORO_NO_CULL"))
         {
             // neighbours that no direction of a cone can leave the cell through (DevScene::vcull).  A cone = the directions with
@@ -808,6 +809,67 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
                 for (auto& t : pool) t.join();
             }
             if ((rc = ctx->upload(cull.data(), cull.size(), &D.vcull))) return bail(rc);
+            // ---- per observer: the kept neighbour entries of its cone, packed (DevScene::vobs_*).  All peel-off walks towards an observer
+            // have ONE direction, hence one cone and one mask per cell
+            int observers = 0;
+            for (int i = 0; i < scene->num_instruments; ++i) observers += scene->instruments[i].same_observer_as_preceding ? 0 : 1;
+            if (observers <= 4 && scene->num_instruments <= 16 && !getenv("PMC_VORO_NO_OBSERVER_LISTS"))
+            {
+                int k = -1;
+                for (int i = 0; i < scene->num_instruments; ++i)
+                {
+                    const pmc_instrument& ins = scene->instruments[i];
+                    if (ins.same_observer_as_preceding)
+                    {
+                        D.vobs_of_inst[i] = (int8_t)k;
+                        continue;
+                    }
+                    ++k;
+                    D.vobs_of_inst[i] = (int8_t)k;
+                    // the cone of the observer's direction: as voroCone (pmc_walk.inc)
+                    const double kx = ins.kobs[0], ky = ins.kobs[1], kz = ins.kobs[2];
+                    const int sgn = (kx < 0. ? 1 : 0) | (ky < 0. ? 2 : 0) | (kz < 0. ? 4 : 0);
+                    const double ax = std::fabs(kx), ay = std::fabs(ky), az = std::fabs(kz);
+                    int pp;
+                    if (ax >= ay)
+                        pp = ay >= az ? 0 : ax >= az ? 1 : 4;
+                    else
+                        pp = ax >= az ? 2 : ay >= az ? 3 : 5;
+                    int cone = sgn * 6 + pp;
+                    if (PMC_VORO_CONES != 48)
+                    {
+                        const double x = std::fmax(ax, std::fmax(ay, az)), z = std::fmin(ax, std::fmin(ay, az)), y = (ax + ay + az) - x - z;
+                        const double a = x - y, b = y - z, c = z;
+                        const int subc = a >= b + c ? 0 : b >= a + c ? 1 : c >= a + b ? 2 : 3;
+                        cone = cone * 4 + subc;
+                    }
+                    std::vector<double> opair, ohead(8 * size_t(ncell), 0.);
+                    opair.reserve(4 * size_t(g.vnbr_start[ncell]) * 2 / 3);
+                    for (int m = 0; m < ncell; ++m)
+                    {
+                        const uint32_t mask = cull[size_t(cone) * size_t(ncell) + size_t(m)];
+                        const int32_t first = int32_t(opair.size() / 4);
+                        for (int q = g.vnbr_start[m]; q < g.vnbr_start[m + 1]; ++q)
+                        {
+                            const int j = q - g.vnbr_start[m];
+                            if (j < 32 && ((mask >> j) & 1u)) continue;
+                            const int mi = g.vnbr_list[q];
+                            double e[4] = {0., 0., 0., 0.};
+                            if (mi >= 0) e[0] = g.site[3 * size_t(mi)], e[1] = g.site[3 * size_t(mi) + 1], e[2] = g.site[3 * size_t(mi) + 2];
+                            const long long bits = mi;
+                            std::memcpy(&e[3], &bits, sizeof(double));
+                            opair.insert(opair.end(), e, e + 4);
+                        }
+                        for (int a = 0; a < 3; ++a) ohead[8 * size_t(m) + a] = g.site[3 * size_t(m) + a];
+                        ohead[8 * size_t(m) + 3] = scene->medium.number_density[m];
+                        const int32_t bounds[2] = {first, int32_t(opair.size() / 4)};
+                        std::memcpy(&ohead[8 * size_t(m) + 4], bounds, sizeof(double));
+                    }
+                    if (opair.empty()) opair.assign(4, 0.);
+                    if ((rc = ctx->upload(opair.data(), opair.size(), &D.vobs_pair[k]))) return bail(rc);
+                    if ((rc = ctx->upload(ohead.data(), ohead.size(), &D.vobs_head[k]))) return bail(rc);
+                }
+            }
         }
         D.vblock_n = g.vblock_n;
         if ((rc = ctx->upload(g.vblock_start, nb3 + 1, &D.vblock_start))) return bail(rc);

@@ -257,6 +257,12 @@ struct DevScene
                                   // words per neighbour from consecutive addresses instead of index -> site gathers
     const double* vhead;          // [num_cells][8]: per cell ONE 64-byte record {site x, y, z, number density, list start | list end
                                   // (two int32 in one double), 3 unused}: what a walk reads of the cell it enters, in one sector
+    // per observer (up to PMC_SORT_OBS; vobs_of_inst[instrument] = its table or -1): the neighbour entries a peel-off walk towards that observer
+    // has to look at -- the ones the mask of the observer's cone keeps, in list order, packed -- and the cells' header records with the bounds of
+    // those lists: such a walk reads no mask and 9 consecutive entries instead of 9 of 15 scattered ones (6.3 -> 3.8 lines per visit)
+    const double* vobs_head[4];
+    const double* vobs_pair[4];
+    int8_t vobs_of_inst[16];
     const uint32_t* vcull;        // [PMC_VORO_CONES][num_cells] (cone-major: a walk keeps its cone, and all peel-off walks towards an observer share
                                   // one: 4 bytes per cell of a 400 KB slice instead of one line per visit): per cell and direction cone (sign pattern of k x order of |k_x|, |k_y|,
                                   // |k_z|) bit j set: the j-th neighbour of the list (j < 32) lies behind every direction of the
