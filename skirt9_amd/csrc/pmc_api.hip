@@ -671,6 +671,10 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
 
     DevScene& D = ctx->dev;
     const pmc_grid& g = scene->grid;
+    // component 0 of the medium system: pmc_scene::media[0] when there are several components (pmc.h: `media` replaces `medium` then, which
+    // the caller may leave zeroed), else pmc_scene::medium.  Its cell densities go into the hot cell records, its dust tables into DevScene.
+    const pmc_medium& med = scene->num_media > 1 ? scene->media[0] : scene->medium;
+    if (!med.number_density) return bail(fail(PMC_ERR_INVALID, "medium component 0 without number_density"));
     std::vector<int32_t> devToCell;  // octree: device cell index -> caller's cell index (else empty: the same numbering)
     D.grid_kind = g.kind;
     D.gx0 = g.xmin, D.gy0 = g.ymin, D.gz0 = g.zmin;
@@ -683,7 +687,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         if ((rc = ctx->upload(g.xv, g.nx + 1, &D.xv))) return bail(rc);
         if ((rc = ctx->upload(g.yv, g.ny + 1, &D.yv))) return bail(rc);
         if ((rc = ctx->upload(g.zv, g.nz + 1, &D.zv))) return bail(rc);
-        if ((rc = ctx->upload(scene->medium.number_density, g.num_cells, &D.cell_density))) return bail(rc);
+        if ((rc = ctx->upload(med.number_density, g.num_cells, &D.cell_density))) return bail(rc);
         D.lds_grid_len = (g.nx + 1) + (g.ny + 1) + (g.nz + 1);
         D.lmax = 0;
         if (int64_t(g.nx) * g.ny * g.nz != int64_t(g.num_cells)) return bail(fail(PMC_ERR_INVALID, "Cartesian grid: cell count does not match the border arrays"));
@@ -696,7 +700,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         for (int m = 0; m < g.num_cells; ++m)
         {
             rec[4 * size_t(m)] = g.site[3 * size_t(m)], rec[4 * size_t(m) + 1] = g.site[3 * size_t(m) + 1];
-            rec[4 * size_t(m) + 2] = g.site[3 * size_t(m) + 2], rec[4 * size_t(m) + 3] = scene->medium.number_density[m];
+            rec[4 * size_t(m) + 2] = g.site[3 * size_t(m) + 2], rec[4 * size_t(m) + 3] = med.number_density[m];
         }
         const size_t nb3 = size_t(g.vblock_n) * g.vblock_n * g.vblock_n;
         for (int m = 0; m < g.num_cells; ++m)
@@ -728,7 +732,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
             for (int m = 0; m < g.num_cells; ++m)
             {
                 for (int a = 0; a < 3; ++a) head[8 * size_t(m) + a] = g.site[3 * size_t(m) + a];
-                head[8 * size_t(m) + 3] = scene->medium.number_density[m];
+                head[8 * size_t(m) + 3] = med.number_density[m];
                 const int32_t bounds[2] = {g.vnbr_start[m], g.vnbr_start[m + 1]};
                 std::memcpy(&head[8 * size_t(m) + 4], bounds, sizeof(double));
             }
@@ -861,7 +865,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
                             opair.insert(opair.end(), e, e + 4);
                         }
                         for (int a = 0; a < 3; ++a) ohead[8 * size_t(m) + a] = g.site[3 * size_t(m) + a];
-                        ohead[8 * size_t(m) + 3] = scene->medium.number_density[m];
+                        ohead[8 * size_t(m) + 3] = med.number_density[m];
                         const int32_t bounds[2] = {first, int32_t(opair.size() / 4)};
                         std::memcpy(&ohead[8 * size_t(m) + 4], bounds, sizeof(double));
                     }
@@ -880,7 +884,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     else
     {
         TreeBuild T;
-        if ((rc = buildTree(g, scene->medium.number_density, T))) return bail(rc);
+        if ((rc = buildTree(g, med.number_density, T))) return bail(rc);
         D.lmax = T.lmax;
         D.root_link = T.rootLink;
         if (size_t(T.cellSlots) > PMC_LINK_MAX_INDEX || T.internals.size() > PMC_LINK_MAX_INDEX)
@@ -906,7 +910,6 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     }
 
     // ---- medium
-    const pmc_medium& med = scene->num_media > 1 ? scene->media[0] : scene->medium;
     D.num_lambda = med.num_lambda;
     if ((rc = ctx->upload(med.lambda_border, med.num_lambda, &D.lambda_border))) return bail(rc);
     if ((rc = ctx->upload(med.sigma_ext, med.num_lambda, &D.sigma_ext))) return bail(rc);

@@ -96,13 +96,9 @@
 #ifndef PMC_PEEL_QCAP
     #define PMC_PEEL_QCAP 128  // task records per wave queue of the peel-off kernel (a power of two >= 128: refilled 64 at a time)
 #endif
-#ifndef PMC_PROP_TRIM
-    #define PMC_PROP_TRIM 5  // segments of a pass-1 walk recorded in LDS (pmc_walk_tree.inc walkPropKernel): what fits next to the coordinate
-                             // table of a 10-level octree in the LDS of a CU (24.6 + 768 x 172 B = 156.7 KB)
-#endif
 #ifndef PMC_PROP_BLOCK
     #define PMC_PROP_BLOCK 768  // lanes per workgroup of the propagation kernel: ONE workgroup of twelve waves per CU -- three per SIMD, what
-                                // the kernel's 157 registers allow -- sharing one coordinate table.  With the slot groups overlapped, 1e8
+                                // the kernel's 157 registers allow -- sharing one coordinate table (24.6 KB at ten levels + 144 bytes of pass-1 checkpoints per lane = 135 KB).  With the slot groups overlapped, 1e8
                                 // packets: 256 lanes (one to three workgroups per CU) 624-626 ms, 512: 645, 768: 602-608, 1024: 638-642
                                 // (profiles/sweeps/r03_batch25_sweep.txt, r03_batch26_sweep.txt)
 #endif
@@ -274,10 +270,10 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
                {reinterpret_cast<const void*>(&walkPeelKernel<true, true>), walkMax},
                {reinterpret_cast<const void*>(&walkPeelKernel2<false>), std::min(walkMax + 16 + pmcPeelQueueBytes(), size_t(160) * 1024)},
                {reinterpret_cast<const void*>(&walkPeelKernel2<true>), std::min(walkMax + 16 + pmcPeelQueueBytes(), size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPropKernel<false, false, false, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPropKernel<false, true, false, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPropKernel<true, false, false, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPropKernel<true, true, false, false>), std::min(walkMax + 16 + PROP_TRIM_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, false, false, false>), std::min(walkMax + 16 + PROP_CKPT_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<false, true, false, false>), std::min(walkMax + 16 + PROP_CKPT_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, false, false, false>), std::min(walkMax + 16 + PROP_CKPT_BYTES, size_t(160) * 1024)},
+               {reinterpret_cast<const void*>(&walkPropKernel<true, true, false, false>), std::min(walkMax + 16 + PROP_CKPT_BYTES, size_t(160) * 1024)},
                {reinterpret_cast<const void*>(&walkPropKernel<false, false, true, false>), walkMax},
                {reinterpret_cast<const void*>(&walkPropKernel<false, true, true, false>), walkMax},
                {reinterpret_cast<const void*>(&walkPropKernel<true, false, true, false>), walkMax},
@@ -336,9 +332,9 @@ extern "C" int pmcWalkBlocksPerCU(int gridKind, int kind, int wide, int block, s
                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPeelKernel<false, false>), block, ldsBytes);
     else if (gridKind == PMC_GRID_OCTREE)
     {
-        // (with the pass-1 records of pmcLaunchProp)
+        // (with the pass-1 checkpoints of pmcLaunchProp)
         const size_t trimOffset = (ldsBytes + 15) & ~size_t(15);
-        if (!getenv("PMC_PROP_NO_TRIM") && trimOffset + PROP_TRIM_BYTES <= size_t(160) * 1024) ldsBytes = trimOffset + PROP_TRIM_BYTES;
+        if (!getenv("PMC_PROP_NO_TRIM") && trimOffset + PROP_CKPT_BYTES <= size_t(160) * 1024) ldsBytes = trimOffset + PROP_CKPT_BYTES;
         e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<true, false, false, false>), block, ldsBytes)
                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<false, false, false, false>), block, ldsBytes);
     }
@@ -466,12 +462,12 @@ extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBas
                                     walkPropKernel<true, true, true, false>,   walkPropKernel<true, false, false, true>, walkPropKernel<true, true, false, true>,
                                     walkPropKernel<true, false, true, true>,   walkPropKernel<true, true, true, true>};
     const Kernel kernel = wide ? wider[storeRf & 7] : narrow[storeRf & 7];
-    // (the pass-1 records follow the grid tables in LDS, if there is room)
+    // (the pass-1 checkpoints follow the grid tables in LDS, if there is room)
     static const bool noTrim = getenv("PMC_PROP_NO_TRIM") != nullptr;  // (tuning aid)
     const size_t trimOffset = (ldsBytes + 15) & ~size_t(15);
-    const bool trim = !noTrim && !ea && !mm && trimOffset + PROP_TRIM_BYTES <= size_t(160) * 1024;
+    const bool trim = !noTrim && !ea && !mm && trimOffset + PROP_CKPT_BYTES <= size_t(160) * 1024;
     RfLogArgs none = {nullptr, nullptr, 0ull, 0, 0u};
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PROP_BLOCK), trim ? trimOffset + PROP_TRIM_BYTES : ldsBytes, stream, slot, slotBase, numSlots, cursor,
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PROP_BLOCK), trim ? trimOffset + PROP_CKPT_BYTES : ldsBytes, stream, slot, slotBase, numSlots, cursor,
                        seed, trim ? (int)trimOffset : -1, rfLog ? *rfLog : none, list);
     return hipGetLastError();
 }
