@@ -31,7 +31,7 @@ extern "C" int pmcPeelBlock(void);
 extern "C" int pmcPropBlock(void);
 extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int taskBase, int numTaskRecords, int taskCounter, uint64_t seed, int grid,
                                     int block, size_t ldsBytes, const WalkStreamArgs* tasks, hipStream_t stream);
-extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int grid, size_t ldsBytes,
+extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int sgn, int grid, size_t ldsBytes,
                                     const PeelRec* sortedRec, const unsigned long long* sortedCount, unsigned long long* xcdCursor, hipStream_t stream);
 extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, const int* list, int cursor, uint64_t seed, int grid,
                                     size_t ldsBytes, const RfLogArgs* rfLog, hipStream_t stream);
@@ -1545,7 +1545,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                             if (sortObs[q] == i) k = q;
                         const bool sorted = peelSorted[g] && !list && k >= 0;
                         HIP_TRY(pmcLaunchPeel(ctx->slot, (ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), base[g], numTasks, sorted ? nullptr : list, PMC_CTR_TASK(g, 1 + i), i,
-                                              peelGrid, ctx->walkLds, sorted ? ctx->peelRec[g][k] : nullptr, sorted ? pmcPeelSortedCount(ctx->peelTemp[g][k]) : nullptr,
+                                              (int)D.inst[i].sgn, peelGrid, ctx->walkLds, sorted ? ctx->peelRec[g][k] : nullptr, sorted ? pmcPeelSortedCount(ctx->peelTemp[g][k]) : nullptr,
                                               sorted && xcdAffinity ? ctx->xcdCursors + (size_t(g) * PMC_SORT_OBS + k) * 8 : nullptr, sp));
                     }
                 HIP_TRY(hipEventRecord(ctx->evJoin[g], sp));

@@ -242,6 +242,16 @@ static size_t pmcPeelQueueBytes()
 {
     return size_t(PMC_PEEL_BLOCK / 64) * PEEL_QBYTES;
 }
+// the peel-off kernel with task queues: one instantiation per sign octant of the observer's direction (bit a of sgn: k_a < 0)
+typedef void (*PeelKernel2)(int, int, int, int, int, int, const int*, PeelSortedArgs);
+static PeelKernel2 peelKernel2For(int wide, int sgn)
+{
+    static const PeelKernel2 narrow[8] = {walkPeelKernel2<false, 0>, walkPeelKernel2<false, 1>, walkPeelKernel2<false, 2>, walkPeelKernel2<false, 3>,
+                                          walkPeelKernel2<false, 4>, walkPeelKernel2<false, 5>, walkPeelKernel2<false, 6>, walkPeelKernel2<false, 7>};
+    static const PeelKernel2 wider[8] = {walkPeelKernel2<true, 0>, walkPeelKernel2<true, 1>, walkPeelKernel2<true, 2>, walkPeelKernel2<true, 3>,
+                                         walkPeelKernel2<true, 4>, walkPeelKernel2<true, 5>, walkPeelKernel2<true, 6>, walkPeelKernel2<true, 7>};
+    return wide ? wider[sgn & 7] : narrow[sgn & 7];
+}
 
 extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
 {
@@ -268,8 +278,6 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
                {reinterpret_cast<const void*>(&walkPeelKernel<true, false>), walkMax},
                {reinterpret_cast<const void*>(&walkPeelKernel<false, true>), walkMax},
                {reinterpret_cast<const void*>(&walkPeelKernel<true, true>), walkMax},
-               {reinterpret_cast<const void*>(&walkPeelKernel2<false>), std::min(walkMax + 16 + pmcPeelQueueBytes(), size_t(160) * 1024)},
-               {reinterpret_cast<const void*>(&walkPeelKernel2<true>), std::min(walkMax + 16 + pmcPeelQueueBytes(), size_t(160) * 1024)},
                {reinterpret_cast<const void*>(&walkPropKernel<false, false, false, false>), std::min(walkMax + 16 + PROP_CKPT_BYTES, size_t(160) * 1024)},
                {reinterpret_cast<const void*>(&walkPropKernel<false, true, false, false>), std::min(walkMax + 16 + PROP_CKPT_BYTES, size_t(160) * 1024)},
                {reinterpret_cast<const void*>(&walkPropKernel<true, false, false, false>), std::min(walkMax + 16 + PROP_CKPT_BYTES, size_t(160) * 1024)},
@@ -318,6 +326,13 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
         hipError_t e = hipFuncSetAttribute(k.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k.lds);
         if (e != hipSuccess) return e;
     }
+    for (int wide = 0; wide < 2; ++wide)
+        for (int sgn = 0; sgn < 8; ++sgn)
+        {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(peelKernel2For(wide, sgn)), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)std::min(walkMax + 16 + pmcPeelQueueBytes(), size_t(160) * 1024));
+            if (e != hipSuccess) return e;
+        }
     return hipSuccess;
 }
 
@@ -422,7 +437,7 @@ extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlo
     return hipGetLastError();
 }
 
-extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int grid, size_t ldsBytes,
+extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int sgn, int grid, size_t ldsBytes,
                                     const PeelRec* sortedRec, const unsigned long long* sortedCount, unsigned long long* xcdCursor, hipStream_t stream)
 {
     static const bool first = getenv("PMC_PEEL_V1") != nullptr;  // (tuning aid: the form with service rounds)
@@ -438,7 +453,8 @@ extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlo
     else
     {
         // (the waves' task queues follow the grid tables in LDS)
-        auto kernel = wide ? walkPeelKernel2<true> : walkPeelKernel2<false>;
+        // (sgn: the sign octant of the observer's direction, DevInstrument::sgn)
+        const PeelKernel2 kernel = peelKernel2For(wide, sgn);
         const size_t queueOffset = (ldsBytes + 15) & ~size_t(15);
         const PeelSortedArgs sorted = {sortedRec, sortedCount, xcdCursor};
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(PMC_PEEL_BLOCK), queueOffset + pmcPeelQueueBytes(), stream, slot, slotBase, numSlots, cursor, obs,
