@@ -66,6 +66,23 @@ def pmc_traffic(packets_per_step):
     return (kib * scale if kib else None), (allkib * scale if allkib else None), os.path.relpath(files[-1], ROOT)
 
 
+def pmc_l2(kernel):
+    """L2 requests, hits, misses and VALU instructions of `kernel` per step of 2e7 packets of the headline workload, from the newest
+    committed counter pass profiles/r*_pmc_l2.csv (rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum SQ_INSTS_VALU SQ_WAVES, a run of its
+    own: tools/run_profile_set.sh, tools/pmc_l2_summary.py); (dict, source file) or (None, None)"""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_l2.csv")),
+                   key=lambda f: [int(x) for x in re.findall(r"[0-9]+", os.path.basename(f))])
+    if not files:
+        return None, None
+    for row in csv.DictReader(open(files[-1])):
+        if kernel.startswith(row["kernel"]):
+            return {k.replace("_per_step_of_2e7_packets", ""): float(v) for k, v in row.items() if k.endswith("_per_step_of_2e7_packets")}, \
+                os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def cpu_baseline(ski_path=SKI, input_dir=None, packets_per_core=100000):
     """photon packets/s of the CPU path on this box's host cores, on a bounded sample (about 10-30 s)"""
     cores = min(os.cpu_count() or 1, 24)  # the reference caps a process at 24 threads (ParallelFactory.cpp:43-50)
@@ -134,7 +151,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from skirt9_amd.engine import Engine
+    from skirt9_amd.engine import Engine, tuning_from_environment
     from skirt9_amd.host import SceneFile, Simulation
 
     rank = int(os.environ.get("RANK", "0"))
@@ -256,6 +273,7 @@ def main():
             dist.barrier()
             if rank == 0:
                 os.unlink(cache)
+        tuning_from_environment()  # (PMC_* variables other than the library's three settings: tuning switches for measurement runs)
         eng = Engine(sim.scene, local_rank)
         setup_s = time.perf_counter() - t_setup   # (rank 0: the whole setup; the others: waiting for it + loading the scene file)
         frames = torch.zeros(sim.frame_size, dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -354,8 +372,11 @@ def main():
         breakdown = None
         if rank == 0 and grid.kind == 2 and not args.no_breakdown:
             eng.close()
-            keep = {k: os.environ.get(k) for k in ("PMC_NUM_GROUPS", "PMC_SERIAL_WALKS")}
-            os.environ["PMC_NUM_GROUPS"], os.environ["PMC_SERIAL_WALKS"] = "1", "1"
+            # (one slot group: a library setting read from the environment at pmc_create; kernels in series: a tuning switch)
+            from skirt9_amd import engine as _engine_module
+            keep = {k: os.environ.get(k) for k in ("PMC_NUM_GROUPS",)}
+            os.environ["PMC_NUM_GROUPS"] = "1"
+            _engine_module.set_tuning("PMC_SERIAL_WALKS", "1")
             try:
                 one = Engine(sim.scene, local_rank)
                 one.bind_frames(frames.data_ptr(), frames.numel())
@@ -373,6 +394,7 @@ def main():
                              "rewalk_visits": c["rewalk_visits"], "cell_visits": c["cell_visits"]}
                 one.close()
             finally:
+                _engine_module.set_tuning("PMC_SERIAL_WALKS", os.environ.get("PMC_SERIAL_WALKS"))
                 for k, v in keep.items():
                     if v is None:
                         os.environ.pop(k, None)
@@ -443,6 +465,21 @@ def main():
                                         "achieved": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "lane_steps_per_s": (b["prop_lane_steps"] if name == "walkPropKernel" else b["peel_lane_steps"]) / (ms * 1e-3),
                                         "measured": f"one slot group, kernels in series, {b['packets']} packets behind the timed region of this run"}
+            # line-rate evidence for that kernel: its L2 requests / hits / misses from the committed counter pass (2e7 packets of the
+            # headline workload), per lane-step of this run's count, and its miss rate against the chip's rate of random lines from
+            # beyond L2 (GATHER_NO_LOCALITY: profiles/microbench/true_gather_mi355x.txt) with the kernel's own serial time
+            if args.config == 2 and args.source == "sersic" and not args.store_radiation_field:
+                l2, l2_source = pmc_l2(name)
+                if l2 and l2.get("TCC_REQ_sum"):
+                    lane_steps_2e7 = (b["prop_lane_steps"] if name == "walkPropKernel" else b["peel_lane_steps"]) * (2e7 / b["packets"])
+                    seconds_2e7 = ms * 1e-3 * (2e7 / b["packets"])
+                    extra["dominant_kernel"].update({
+                        "l2_requests_per_lane_step": l2["TCC_REQ_sum"] / lane_steps_2e7,
+                        "l2_miss_frac": l2["TCC_MISS_sum"] / l2["TCC_REQ_sum"],
+                        "lines_per_visit": l2["TCC_MISS_sum"] / lane_steps_2e7,
+                        "line_rate_frac": l2["TCC_MISS_sum"] / seconds_2e7 / GATHER_NO_LOCALITY,
+                        "valu_instructions_per_lane_step": l2["SQ_INSTS_VALU"] / lane_steps_2e7,
+                        "l2_counters_measured_in_run": False, "l2_counters_source": l2_source})
             extra["serial_kernel_ms_per_step"] = {"walkPropKernel": b["prop_ms"] * scale, "walkPeelKernel2": b["peel_ms"] * scale,
                                                   "launch + transition + cycle start + scan": b["transition_side_ms"] * scale,
                                                   "segment": b["segment_ms"] * scale}

@@ -330,8 +330,6 @@ int pmc_reset_counters(pmc_ctx* ctx);
 /* Walk one ray on the device with the same traversal code the photon loop uses; k is normalised by the caller.
    Writes up to cap segments (cell index m or -1, length ds) and the number found to *n. */
 int pmc_trace_ray(pmc_ctx* ctx, const double r[3], const double k[3], int32_t* m, double* ds, int32_t cap, int32_t* n);
-/* tuning knobs (0 = default): threads per workgroup and workgroups of the persistent walk kernel */
-int pmc_set_launch(pmc_ctx* ctx, int32_t block, int32_t grid);
 /* number of photon histories kept in flight on the device (default 8 Mi; environment PMC_NUM_SLOTS).  The slots are
    divided into slot groups (default 3; environment PMC_NUM_GROUPS) whose generations run on separate streams */
 int pmc_set_num_slots(pmc_ctx* ctx, int64_t num_slots);
@@ -344,28 +342,10 @@ int pmc_last_timing(pmc_ctx* ctx, float* total_ms, float* walk_ms, float* transi
    (MediumSystem::setExtinctionOpticalDepths + the interaction point), HIP events, summed over the generations; the two run
    side by side on two streams of a slot group, so the spans overlap.  0 on other grids. */
 int pmc_last_walk_timing(pmc_ctx* ctx, float* peel_ms, float* prop_ms);
-/* counted work of the octree walk kernels since create/reset: a wave-step is one pass of a wavefront through the step
-   code, a lane-step one cell visit by one lane (lane_steps / (64 wave_steps) = the fraction of the lanes that held a walk);
-   rounds = bookkeeping rounds (finished walks stored, next walks taken up).  Propagation lane-steps include the second
-   pass over a forced-scattering path.  No reference counterpart (roofline inputs). */
-typedef struct pmc_walk_work_values
-{
-    uint64_t peel_wave_steps, peel_lane_steps, peel_rounds;
-    uint64_t prop_wave_steps, prop_lane_steps, prop_rounds;
-} pmc_walk_work_values;
-int pmc_walk_work(pmc_ctx* ctx, pmc_walk_work_values* out);
-/* Tuning aid: DEVICE addresses of the octree walk's hot table (see skirt9_amd/csrc/pmc_device.h) and of the first cells of the propagation walks the last generations left in
-   the task records -- so that profiles/microbench/bridge.hip can replay the walk's memory accesses on the scene's own tables.
-   No reference counterpart; nothing in the product reads it. */
-typedef struct pmc_debug_table_values
-{
-    const void* cell_table;   /* [cell_slots] 32-byte records (pmc_device.h CellRec) */
-    int64_t cell_slots;
-    int64_t loose_base;       /* = cell_slots (the octet-line table of profiles/experiments/r04_octet_line_table.patch: first loose leaf) */
-    const int32_t* task_cell; /* [num_slots] first cell of the propagation walk of every slot (stale after the segment's end) */
-    int64_t num_slots;
-} pmc_debug_table_values;
-int pmc_debug_tables(pmc_ctx* ctx, pmc_debug_table_values* out);
+/* (Tuning aids -- launch geometry, counted walk work, device addresses of the hot tables for the microbenchmarks, and the
+   switches that select alternative code paths for A/B measurements and cross-checks -- are declared in pmc_tuning.h; a caller that
+   replaces runPrimaryEmission needs none of them.  From the ENVIRONMENT the library reads three settings only: PMC_NUM_SLOTS,
+   PMC_NUM_GROUPS and PMC_STAT_POOL_BLOCKS.) */
 
 /* ---------------------------------------------------------------- several GPUs: one segment over RCCL ---- */
 

@@ -11,6 +11,7 @@
 
 #include "pmc_device.h"
 #include "../../include/pmc_layout.h"
+#include "../../include/pmc_tuning.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -21,7 +22,43 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <map>
 #include <vector>
+
+// ---- tuning switches (include/pmc_tuning.h): a process-wide table set through pmc_tuning_set; the library reads three settings
+// from the environment (PMC_NUM_SLOTS, PMC_NUM_GROUPS, PMC_STAT_POOL_BLOCKS) and nothing else
+namespace
+{
+    std::mutex g_tuneMutex;
+    std::map<std::string, std::string>& tuneTable()
+    {
+        static std::map<std::string, std::string> table;
+        return table;
+    }
+}
+// the value of a tuning switch, or null (the pointer stays valid until the switch is set again or removed)
+extern "C" const char* pmcTune(const char* name)
+{
+    std::lock_guard<std::mutex> lock(g_tuneMutex);
+    auto& table = tuneTable();
+    auto at = table.find(name);
+    return at == table.end() ? nullptr : at->second.c_str();
+}
+extern "C" int pmc_tuning_set(const char* name, const char* value)
+{
+    if (!name) return PMC_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(g_tuneMutex);
+    if (value)
+        tuneTable()[name] = value;
+    else
+        tuneTable().erase(name);
+    return PMC_OK;
+}
+extern "C" void pmc_tuning_clear(void)
+{
+    std::lock_guard<std::mutex> lock(g_tuneMutex);
+    tuneTable().clear();
+}
 
 extern "C" hipError_t pmcUploadScene(int slot, const DevScene* scene, hipStream_t stream);
 extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds);
@@ -38,6 +75,7 @@ extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBas
 extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n,
                                        int numParts, void* temp, int numCU, hipStream_t stream);
 extern "C" int pmcPeelHasQueues(int wide, size_t ldsBytes);
+extern "C" int pmcExperimentBuild(void);
 extern "C" const unsigned long long* pmcPeelSortedCount(void* temp);
 extern "C" size_t pmcPeelSortTempBytes();
 extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlots, PeelSortArgs* ps, PeelRec* const* sorted, int32_t* const* lists, void* const* temp,
@@ -45,9 +83,12 @@ extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlo
 extern "C" size_t pmcRfTempBytes(int numParts);
 extern "C" int pmcRfMaxParts();
 extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, const int* list, int listLen, int maxBlocks,
-                                          size_t ldsBytes, hipStream_t stream);
+                                          size_t ldsBytes, const StatLogArgs* statLog, hipStream_t stream);
 extern "C" hipError_t pmcLaunchLaunch(int slot, int slotBase, int numSlots, int group, uint64_t first, uint64_t count, uint64_t seed, int initial,
-                                      int maxBlocks, size_t ldsBytes, hipStream_t stream);
+                                      int maxBlocks, size_t ldsBytes, const StatLogArgs* statLog, hipStream_t stream);
+extern "C" hipError_t pmcLaunchStatFlush(int slot, const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n,
+                                         int numParts, void* temp, int numCU, const uint32_t* chunkFill, hipStream_t stream);
+extern "C" int pmcStatBucketBits();
 extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, int numSlots, int listCounter, int* listOut, const int* listIn,
                                           int listLen, int maxBlocks, size_t ldsBytes, const PeelSortArgs* sort, hipStream_t stream);
 extern "C" hipError_t pmcLaunchTrace(int slot, int gridKind, int wide, int uniform, const double r[3], const double k[3],
@@ -119,6 +160,8 @@ struct pmc_ctx
     int64_t numSlots{0};         // requested pool size
     int64_t allocatedSlots{0};   // size of the allocated slot arrays
     unsigned long long* pinned{nullptr};
+    unsigned long long internalErrorsSeen{0};
+    bool groupsConfigured{false};         // the number of slot groups was set explicitly (PMC_NUM_GROUPS)
     unsigned long long overflowsSeen{0};  // statistics-list overflows already reported (pmc_run_primary)
     int32_t* statPoolIota{nullptr};       // 0, 1, 2, ...: the free list of a statistics pool none of whose blocks is in use
     int64_t statPoolBlocks{0};
@@ -136,6 +179,14 @@ struct pmc_ctx
     unsigned long long* xcdCursors{nullptr};  // [PMC_MAX_GROUPS][PMC_SORT_OBS][8] the peel-off kernels' cursors over the eighths of the sorted records
     int peelCap[PMC_MAX_GROUPS]{};
     size_t rfTempBytes{0};
+    // statistics log per slot group (pmc_device.h StatLogArgs): the log and its partitioned copy, the sort's counters
+    uint32_t* statKeys[PMC_MAX_GROUPS][2]{};
+    double* statVals[PMC_MAX_GROUPS][2]{};
+    unsigned long long statCap[PMC_MAX_GROUPS]{};
+    void* statTemp[PMC_MAX_GROUPS]{};
+    unsigned long long* statWaveBase[PMC_MAX_GROUPS]{};
+    uint32_t* statWaveFill[PMC_MAX_GROUPS]{};
+    uint32_t* statChunkFill[PMC_MAX_GROUPS]{};
 
     template<typename T> int upload(const T* host, size_t count, const T** out)
     {
@@ -270,9 +321,9 @@ namespace
         {
             const int n = g.num_cells;
             T.perm.assign(n, -1);
-            const char* order = getenv("PMC_CELL_ORDER");
+            const char* order = pmcTune("PMC_CELL_ORDER");
             int gb = -1;
-            if (const char* env = getenv("PMC_CELL_SHUFFLE")) gb = atoi(env);
+            if (const char* env = pmcTune("PMC_CELL_SHUFFLE")) gb = atoi(env);
             if (gb >= 0 && gb <= 16)
             {
                 const int groupSize = 1 << gb;
@@ -617,6 +668,12 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     if (!scene || !out) return fail(PMC_ERR_INVALID, "null argument");
     *out = nullptr;
     if (scene->abi_version != PMC_ABI_VERSION) return fail(PMC_ERR_INVALID, "pmc_scene ABI version mismatch");
+    if (pmcExperimentBuild())
+    {
+        static bool said = false;
+        if (!said) fprintf(stderr, "libpmc: this library was built with an ablation / perturbation macro (a tuning experiment): its results are NOT those of the engine\n");
+        said = true;
+    }
     if (scene->num_media > PMC_MAX_MEDIA) return fail(PMC_ERR_UNSUPPORTED, "more than PMC_MAX_MEDIA medium components");
     if (scene->num_media > 1 && !scene->media) return fail(PMC_ERR_INVALID, "num_media > 1 without pmc_scene::media");
     if (scene->num_instruments < 1 || scene->num_instruments > PMC_MAX_INSTRUMENTS)
@@ -665,7 +722,11 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     for (int g = 0; g < PMC_MAX_GROUPS; ++g)
         for (hipEvent_t* ev : {&ctx->evA[g], &ctx->evB[g], &ctx->evC[g], &ctx->evJoin[g], &ctx->evProp[g]})
             if (hipEventCreate(ev) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipEventCreate failed"));
-    if (const char* env = getenv("PMC_NUM_GROUPS")) ctx->numGroups = std::min(PMC_MAX_GROUPS, std::max(1, atoi(env)));
+    if (const char* env = getenv("PMC_NUM_GROUPS"))
+    {
+        ctx->numGroups = std::min(PMC_MAX_GROUPS, std::max(1, atoi(env)));
+        ctx->groupsConfigured = true;  // (an explicit setting: also a Voronoi scene runs with it)
+    }
     if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), 16 * sizeof(unsigned long long)) != hipSuccess)
         return bail(fail(PMC_ERR_DEVICE, "hipHostMalloc failed"));
 
@@ -740,7 +801,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         }
         D.vcull = nullptr;
         for (int i = 0; i < 16; ++i) D.vobs_of_inst[i] = -1;
-        if (!getenv("PMC_VORO_NO_CULL"))
+        if (!pmcTune("PMC_VORO_NO_CULL"))
         {
             // neighbours that no direction of a cone can leave the cell through (DevScene::vcull).  A cone = the directions with
             // one sign pattern and one order of |k_x|, |k_y|, |k_z|: the non-negative combinations of three extreme rays, so
@@ -817,7 +878,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
             // have ONE direction, hence one cone and one mask per cell
             int observers = 0;
             for (int i = 0; i < scene->num_instruments; ++i) observers += scene->instruments[i].same_observer_as_preceding ? 0 : 1;
-            if (observers <= 4 && scene->num_instruments <= 16 && !getenv("PMC_VORO_NO_OBSERVER_LISTS"))
+            if (observers <= 4 && scene->num_instruments <= 16 && !pmcTune("PMC_VORO_NO_OBSERVER_LISTS"))
             {
                 int k = -1;
                 for (int i = 0; i < scene->num_instruments; ++i)
@@ -1043,7 +1104,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     // one wavelength for every history: its dust properties are found here once, as launchHistory finds them (DustMix::indexForLambda:
     // NR::locateClip on the index borders)
     auto sourceOf = [&](int si) -> const pmc_source& { return numSources > 1 ? scene->sources[si] : scene->source; };
-    D.mono = (sourceOf(0).lambda_mode == PMC_LAMBDA_OLIGO && getenv("PMC_NO_MONO") == nullptr) ? 1 : 0;
+    D.mono = (sourceOf(0).lambda_mode == PMC_LAMBDA_OLIGO && pmcTune("PMC_NO_MONO") == nullptr) ? 1 : 0;
     for (int si = 0; si < numSources && D.mono; ++si)
         if (sourceOf(si).num_oligo != 1 || sourceOf(si).oligo_lambda[0] != sourceOf(0).oligo_lambda[0]) D.mono = 0;
     D.mono_lambda = D.mono_ext = D.mono_sca = D.mono_asym = D.mono_abs = 0.;
@@ -1208,7 +1269,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         // rate of random gathers, which falls when too many of them are in flight -- 32 MB table, 8 / 16 / 32 waves per CU:
         // 1.9 / 0.94 / 0.83e11 records/s, profiles/microbench/gather_modes_mi355x.txt -- and the kernels of three slot groups
         // overlap; 1 / 2 / 3 per CU: 697 / 720 / 756 ms per 1e8 packets)
-        if (const char* env = getenv("PMC_WALK_BLOCKS_PER_CU")) perCU = std::min(perCU, std::max(1, atoi(env)));  // tuning aid
+        if (const char* env = pmcTune("PMC_WALK_BLOCKS_PER_CU")) perCU = std::min(perCU, std::max(1, atoi(env)));  // tuning aid
         else perCU = std::min(perCU, D.grid_kind == PMC_GRID_OCTREE ? 1 : 3);
         ctx->grid = ctx->numCU * perCU;
         if (D.grid_kind == PMC_GRID_OCTREE)
@@ -1217,7 +1278,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
             // (one workgroup of 512 lanes per CU: with the pipelined step more resident waves only queue up in the memory
             // system -- 1 / 2 / 3 per CU: 97 / 111 / 124 ms per 5e7 packets, profiles/README.md)
             peelPerCU = std::min(std::max(peelPerCU, 1), 1);
-            if (const char* env = getenv("PMC_PEEL_BLOCKS_PER_CU")) peelPerCU = std::max(1, atoi(env));
+            if (const char* env = pmcTune("PMC_PEEL_BLOCKS_PER_CU")) peelPerCU = std::max(1, atoi(env));
             ctx->peelGrid = ctx->numCU * peelPerCU;
         }
     }
@@ -1296,8 +1357,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     hipStream_t st = ctx->stream;
     unsigned long long* ctr = D.counters;
     float walkMs = 0, transMs = 0, peelMs = 0, propMs = 0;
-    const bool serialWalks = getenv("PMC_SERIAL_WALKS") != nullptr;  // tuning aid: peel-off and propagation kernels one after the other
-    const bool genDump = getenv("PMC_GEN_DUMP") != nullptr;  // tuning aid: live slots and kernel times of every generation
+    const bool serialWalks = pmcTune("PMC_SERIAL_WALKS") != nullptr;  // tuning aid: peel-off and propagation kernels one after the other
+    const bool genDump = pmcTune("PMC_GEN_DUMP") != nullptr;  // tuning aid: live slots and kernel times of every generation
     int generations = 0;
     // ---- slot groups: group g owns the slots [base[g], base[g] + size[g]) and the stream groupStream[g].  The
     // generations of different groups are independent (histories come from one shared cursor), so while the host
@@ -1311,7 +1372,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         // with one / two / three groups)
         int observers = 0;
         for (int i = 0; i < D.num_instruments; ++i) observers += D.inst[i].same_observer ? 0 : 1;
-        if (D.grid_kind == PMC_GRID_VORONOI && observers <= PMC_SORT_OBS && getenv("PMC_NUM_GROUPS") == nullptr && getenv("PMC_NO_PEEL_SORT") == nullptr) G = 1;
+        if (D.grid_kind == PMC_GRID_VORONOI && observers <= PMC_SORT_OBS && !ctx->groupsConfigured && pmcTune("PMC_NO_PEEL_SORT") == nullptr) G = 1;
     }
     int base[PMC_MAX_GROUPS], size[PMC_MAX_GROUPS];
     bool active[PMC_MAX_GROUPS], haveWalk[PMC_MAX_GROUPS];
@@ -1326,14 +1387,14 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     // are written by the cycle start kernel in slot order, sorted by detector tile, and read in tile order by the peel-off kernel)
     bool peelSorted[PMC_MAX_GROUPS] = {false, false, false, false};
     int numSortObs = 0, sortObs[PMC_SORT_OBS] = {0, 0, 0, 0};
-    const bool xcdAffinity = getenv("PMC_NO_XCD_AFFINITY") == nullptr;
+    const bool xcdAffinity = pmcTune("PMC_NO_XCD_AFFINITY") == nullptr;
     if (!ctx->xcdCursors)
     {
         int rc;
         if ((rc = ctx->allocate<unsigned long long>(size_t(PMC_MAX_GROUPS) * PMC_SORT_OBS * 8, &ctx->xcdCursors, true, &ctx->rfAllocations))) return rc;
     }
     const bool octree = D.grid_kind == PMC_GRID_OCTREE;
-    if (getenv("PMC_NO_PEEL_SORT") == nullptr && (!octree || pmcPeelHasQueues((ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), ctx->walkLds)))
+    if (pmcTune("PMC_NO_PEEL_SORT") == nullptr && (!octree || pmcPeelHasQueues((ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), ctx->walkLds)))
     {
         int observers = 0;
         for (int i = 0; i < D.num_instruments; ++i)
@@ -1346,8 +1407,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     }
     int listHalf[PMC_MAX_GROUPS] = {0, 0, 0, 0};  // the half of liveList that holds the group's current list
     int listTasksPerLane = 1;  // walks per lane that size the walk kernels' grids in a sparse generation
-    if (const char* env = getenv("PMC_LIST_TASKS_PER_LANE")) listTasksPerLane = std::max(1, atoi(env));
-    const bool sparseLists = D.grid_kind == PMC_GRID_OCTREE && getenv("PMC_NO_LIVE_LISTS") == nullptr;
+    if (const char* env = pmcTune("PMC_LIST_TASKS_PER_LANE")) listTasksPerLane = std::max(1, atoi(env));
+    const bool sparseLists = D.grid_kind == PMC_GRID_OCTREE && pmcTune("PMC_NO_LIVE_LISTS") == nullptr;
     {
         const int per = ((numSlots / G) + PMC_TRANSITION_ALIGN - 1) / PMC_TRANSITION_ALIGN * PMC_TRANSITION_ALIGN;
         for (int g = 0; g < G; ++g)
@@ -1400,18 +1461,27 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     // which is partitioned by key range and summed after the generation.  128 entries per slot (config 2: 60 per propagation
     // walk on average); a wave that finds the log full falls back to atomic adds into the table.
     const int64_t rfSize = ctx->rfSize;
-    // (tables beyond 2^25 entries have more partitions than the counting sort's LDS histogram holds: atomics)
+    // (tables beyond 2^26 entries have more partitions than the counting sort's LDS histogram holds: atomics)
     // (the keys of the log count cells in the device numbering: cell_slots of them, padding included)
     const int64_t rfKeys = D.grid_kind == PMC_GRID_OCTREE ? int64_t(D.cell_slots) * D.rf_num_lambda : rfSize;
     const int64_t rfParts = (rfKeys + (int64_t(1) << PMC_RF_BUCKET_BITS) - 1) >> PMC_RF_BUCKET_BITS;
-    const bool rfLogged = D.rf_store && D.grid_kind == PMC_GRID_OCTREE && rfParts <= pmcRfMaxParts() && getenv("PMC_RF_ATOMICS") == nullptr;
+    const bool rfLogged = D.rf_store && D.grid_kind == PMC_GRID_OCTREE && rfParts <= pmcRfMaxParts() && pmcTune("PMC_RF_ATOMICS") == nullptr;
+    if (D.rf_store && D.grid_kind == PMC_GRID_OCTREE && rfParts > pmcRfMaxParts())
+    {
+        // (a table beyond 2^26 entries: one atomic per contribution, several times slower -- said once, not silently)
+        static bool said = false;
+        if (!said)
+            fprintf(stderr, "libpmc: the radiation field table has %lld entries, more than the log's counting sort partitions (%d x %d): contributions are added atomically\n",
+                    (long long)rfKeys, pmcRfMaxParts(), 1 << PMC_RF_BUCKET_BITS);
+        said = true;
+    }
     const int rfBuckets = rfLogged ? int(rfParts) : 0;
     const uint32_t rfPadKey = uint32_t(rfBuckets) << PMC_RF_BUCKET_BITS;
     if (rfLogged)
         for (int g = 0; g < G; ++g)
         {
             unsigned long long perSlot = 128ull;
-            if (const char* env = getenv("PMC_RF_LOG_PER_SLOT")) perSlot = std::max(1, atoi(env));  // (tests: a log that overflows)
+            if (const char* env = pmcTune("PMC_RF_LOG_PER_SLOT")) perSlot = std::max(1, atoi(env));  // (tests: a log that overflows)
             // (positions in the partitioned log are 32-bit: at most 2^31 - 1 entries, in whole chunks; a wave that finds the log
             // full adds its contributions atomically)
             const unsigned long long want = std::min<unsigned long long>(
@@ -1479,6 +1549,84 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         HIP_TRY(pmcLaunchRfFlush(ctx->slot, ctx->rfKeys[g][0], ctx->rfVals[g][0], ctx->rfKeys[g][1], ctx->rfVals[g][1], n, rfBuckets, ctx->rfTemp[g], ctx->numCU, sg));
         return PMC_OK;
     };
+    // ---- statistics: the contributions of ended histories go to a log per slot group (pmc_device.h StatLogArgs), which is partitioned by
+    // record range and summed in LDS when it has filled up, and at the end of the segment
+    const int statBits = pmcStatBucketBits();
+    const int64_t statParts = (D.stat_acc_records + (int64_t(1) << statBits) - 1) >> statBits;
+    const bool statLogged = D.any_stats && D.stat_acc_records > 0 && statParts <= pmcRfMaxParts() && pmcTune("PMC_STAT_ATOMICS") == nullptr;
+    if (statLogged)
+        for (int g = 0; g < G; ++g)
+        {
+            // (3.7 entries per history on configs[1]: the log of a group holds a segment of 1e8 packets; it is flushed when half full)
+            unsigned long long want = (128ull << 20);
+            if (const char* env = pmcTune("PMC_STAT_LOG_ENTRIES")) want = std::max(1, atoi(env));  // (tests: a log that overflows)
+            want = std::max<unsigned long long>((want + PMC_RF_LOG_CHUNK - 1) / PMC_RF_LOG_CHUNK, 1ull) * PMC_RF_LOG_CHUNK;
+            if (ctx->statCap[g] == want && ctx->statTemp[g] && ctx->statChunkFill[g]) continue;
+            HIP_TRY(hipDeviceSynchronize());
+            auto release = [&](void* p) {
+                if (!p) return;
+                hipFree(p);
+                auto at = std::find(ctx->rfAllocations.begin(), ctx->rfAllocations.end(), p);
+                if (at != ctx->rfAllocations.end()) ctx->rfAllocations.erase(at);
+            };
+            for (int k = 0; k < 2; ++k)
+            {
+                release(ctx->statKeys[g][k]), release(ctx->statVals[g][k]);
+                ctx->statKeys[g][k] = nullptr, ctx->statVals[g][k] = nullptr;
+            }
+            release(ctx->statChunkFill[g]);
+            ctx->statChunkFill[g] = nullptr;
+            ctx->statCap[g] = 0;
+            size_t freeBytes = 0, totalBytes = 0;
+            bool room = hipMemGetInfo(&freeBytes, &totalBytes) != hipSuccess || size_t(want) * 24 + (size_t(2) << 30) <= freeBytes;
+            room = room && ctx->allocate<uint32_t>(want / PMC_RF_LOG_CHUNK, &ctx->statChunkFill[g], false, &ctx->rfAllocations) == PMC_OK;
+            if (room && !ctx->statWaveBase[g])
+                room = ctx->allocate<unsigned long long>(PMC_STAT_LOG_WAVES, &ctx->statWaveBase[g], true, &ctx->rfAllocations) == PMC_OK
+                       && ctx->allocate<uint32_t>(PMC_STAT_LOG_WAVES, &ctx->statWaveFill[g], false, &ctx->rfAllocations) == PMC_OK;
+            for (int k = 0; k < 2 && room; ++k)
+                room = ctx->allocate<uint32_t>(want, &ctx->statKeys[g][k], false, &ctx->rfAllocations) == PMC_OK
+                       && ctx->allocate<double>(want, &ctx->statVals[g][k], false, &ctx->rfAllocations) == PMC_OK;
+            if (room && !ctx->statTemp[g])
+            {
+                uint8_t* t = nullptr;
+                room = ctx->allocate<uint8_t>(pmcRfTempBytes(pmcRfMaxParts()), &t, false, &ctx->rfAllocations) == PMC_OK;
+                ctx->statTemp[g] = t;
+            }
+            if (!room)
+            {
+                // (no room for the log: this group's sums are added atomically)
+                for (int k = 0; k < 2; ++k)
+                {
+                    release(ctx->statKeys[g][k]), release(ctx->statVals[g][k]);
+                    ctx->statKeys[g][k] = nullptr, ctx->statVals[g][k] = nullptr;
+                }
+                continue;
+            }
+            ctx->statCap[g] = want;
+        }
+    auto statLogOf = [&](int g) -> StatLogArgs {
+        StatLogArgs a = {nullptr, nullptr, 0ull, 0, nullptr, nullptr, nullptr};
+        if (statLogged && ctx->statCap[g])
+            a = {ctx->statKeys[g][0], ctx->statVals[g][0], ctx->statCap[g], PMC_CTR_STATLOG(g), ctx->statWaveBase[g], ctx->statWaveFill[g], ctx->statChunkFill[g]};
+        return a;
+    };
+    // an empty log: no wave holds a chunk, every chunk counts as full until a wave leaves it open or short
+    auto statLogReset = [&](int g, hipStream_t stream) -> int {
+        if (!statLogged || !ctx->statCap[g]) return PMC_OK;
+        HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_STATLOG(g), 0, sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->statWaveFill[g]), (int)PMC_STAT_NO_CHUNK, PMC_STAT_LOG_WAVES, stream));
+        HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->statChunkFill[g]), PMC_RF_LOG_CHUNK, size_t(ctx->statCap[g] / PMC_RF_LOG_CHUNK), stream));
+        return PMC_OK;
+    };
+    // the log of group g (`claimed` entries) -> accumulator records, on `stream`; the cursor starts again at zero
+    auto statFlush = [&](int g, unsigned long long claimed, hipStream_t stream) -> int {
+        if (!statLogged || !ctx->statCap[g]) return PMC_OK;
+        const unsigned long long n = std::min(claimed, ctx->statCap[g]) / PMC_RF_LOG_CHUNK * PMC_RF_LOG_CHUNK;
+        if (n)
+            HIP_TRY(pmcLaunchStatFlush(ctx->slot, ctx->statKeys[g][0], ctx->statVals[g][0], ctx->statKeys[g][1], ctx->statVals[g][1], n, int(statParts), ctx->statTemp[g],
+                                       ctx->numCU, ctx->statChunkFill[g], stream));
+        return statLogReset(g, stream);
+    };
     // ---- statistics: every slot group starts with its share of the pool of list blocks, all of them free
     if (D.any_stats && ctx->statPoolBlocks)
     {
@@ -1502,16 +1650,18 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         HIP_TRY(hipMemcpyAsync(ctr + PMC_CTR_STATFREE(0), freeCount, sizeof(freeCount), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));  // (freeCount lives on this frame)
     }
+    for (int g = 0; g < G; ++g)
+        if (int rc = statLogReset(g, st)) return rc;
     HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_HISTORY, 0, sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(ctr + 32, 0, 4 * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(0, 0), 0, PMC_CTR_TASKS_PER_GROUP * PMC_MAX_GROUPS * sizeof(unsigned long long), st));
     HIP_TRY(hipEventRecord(ctx->evStart, st));
     int launchBlocks = ctx->numCU * 4;  // persistent launch workgroups, as the transition kernel's
-    if (const char* env = getenv("PMC_LAUNCH_BLOCKS_PER_CU")) launchBlocks = ctx->numCU * std::max(1, atoi(env));
+    if (const char* env = pmcTune("PMC_LAUNCH_BLOCKS_PER_CU")) launchBlocks = ctx->numCU * std::max(1, atoi(env));
     int cycleBlocks = ctx->numCU * 4;  // persistent cycle start workgroups (grid tables staged once per workgroup)
-    if (const char* env = getenv("PMC_CYCLE_BLOCKS_PER_CU")) cycleBlocks = ctx->numCU * std::max(1, atoi(env));
+    if (const char* env = pmcTune("PMC_CYCLE_BLOCKS_PER_CU")) cycleBlocks = ctx->numCU * std::max(1, atoi(env));
     int transitionBlocks = ctx->numCU * 4;  // persistent transition workgroups (tables staged once per workgroup)
-    if (const char* env = getenv("PMC_TRANSITION_BLOCKS_PER_CU")) transitionBlocks = ctx->numCU * std::max(1, atoi(env));
+    if (const char* env = pmcTune("PMC_TRANSITION_BLOCKS_PER_CU")) transitionBlocks = ctx->numCU * std::max(1, atoi(env));
     auto enqueue = [&](int g, bool initial) -> int {
         hipStream_t sg = ctx->groupStream[g];
         // the list of live slots the previous generation left (as many as its live count, which came back with the stream)
@@ -1522,6 +1672,12 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             // (the radiation-field log of the group's previous generation: its size came back with the live count)
             if (int rc = rfFlush(g, ctx->pinned[PMC_MAX_GROUPS + g])) return rc;
             ctx->pinned[PMC_MAX_GROUPS + g] = 0;
+            // (the statistics log of the group, once half full: its fill came back with the live count)
+            if (ctx->pinned[2 * PMC_MAX_GROUPS + g] > ctx->statCap[g] / 2)
+            {
+                if (int rc = statFlush(g, ctx->pinned[2 * PMC_MAX_GROUPS + g], sg)) return rc;
+                ctx->pinned[2 * PMC_MAX_GROUPS + g] = 0;
+            }
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(g, 0), 0, PMC_CTR_TASKS_PER_GROUP * sizeof(unsigned long long), sg));  // task cursors
             if (ctx->xcdCursors) HIP_TRY(hipMemsetAsync(ctx->xcdCursors + size_t(g) * PMC_SORT_OBS * 8, 0, PMC_SORT_OBS * 8 * sizeof(unsigned long long), sg));
             HIP_TRY(hipEventRecord(ctx->evA[g], sg));
@@ -1574,14 +1730,15 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             haveWalk[g] = true;
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_LIVE(g), 0, sizeof(unsigned long long), sg));
-            HIP_TRY(pmcLaunchTransition(ctx->slot, base[g], size[g], g, seed, listIn, listLen, transitionBlocks, ctx->transitionLds, sg));
-            if (!listIn) HIP_TRY(pmcLaunchLaunch(ctx->slot, base[g], size[g], g, first, count, seed, 0, launchBlocks, ctx->launchLds, sg));
+            const StatLogArgs statLog = statLogOf(g);
+            HIP_TRY(pmcLaunchTransition(ctx->slot, base[g], size[g], g, seed, listIn, listLen, transitionBlocks, ctx->transitionLds, &statLog, sg));
+            if (!listIn) HIP_TRY(pmcLaunchLaunch(ctx->slot, base[g], size[g], g, first, count, seed, 0, launchBlocks, ctx->launchLds, &statLog, sg));
         }
         else
         {
             if (g > 0) HIP_TRY(hipStreamWaitEvent(sg, ctx->evStart, 0));
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
-            HIP_TRY(pmcLaunchLaunch(ctx->slot, base[g], size[g], g, first, count, seed, 1, (size[g] + 255) / 256, ctx->launchLds, sg));
+            HIP_TRY(pmcLaunchLaunch(ctx->slot, base[g], size[g], g, first, count, seed, 1, (size[g] + 255) / 256, ctx->launchLds, nullptr, sg));
         }
         // every live slot of the group is at the start of a cycle now: the start states of its walks -- and, once the live slots
         // of the previous generation were fewer than half of the group's, their list for the next generation.  (The launch kernel
@@ -1595,6 +1752,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         PeelSortArgs sortArgs;
         std::memset(&sortArgs, 0, sizeof(sortArgs));
         sortArgs.numObs = numSortObs;
+        sortArgs.cap = (uint32_t)ctx->peelCap[g];
         for (int i = 0; i < 16; ++i) sortArgs.sortIndex[i] = -1;
         for (int k = 0; k < numSortObs; ++k) sortArgs.obs[k] = sortObs[k], sortArgs.sortIndex[sortObs[k]] = (int8_t)k;
         sortArgs.centre[0] = 0.5 * (D.gx0 + D.gx1), sortArgs.centre[1] = 0.5 * (D.gy0 + D.gy1), sortArgs.centre[2] = 0.5 * (D.gz0 + D.gz1);
@@ -1612,6 +1770,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         HIP_TRY(hipMemcpyAsync(ctx->pinned + g, ctr + PMC_CTR_LIVE(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
         if (rfLogged && !initial)
             HIP_TRY(hipMemcpyAsync(ctx->pinned + PMC_MAX_GROUPS + g, ctr + PMC_CTR_RFLOG(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
+        if (statLogged && !initial && ctx->statCap[g])
+            HIP_TRY(hipMemcpyAsync(ctx->pinned + 2 * PMC_MAX_GROUPS + g, ctr + PMC_CTR_STATLOG(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
         return PMC_OK;
     };
     // on any failure: no kernel of this segment may still be running (or be timed) when the call returns
@@ -1673,14 +1833,19 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         }
         return PMC_OK;
     };
-    for (int g = 0; g < PMC_MAX_GROUPS; ++g) ctx->pinned[PMC_MAX_GROUPS + g] = 0;
+    for (int g = 0; g < PMC_MAX_GROUPS; ++g) ctx->pinned[PMC_MAX_GROUPS + g] = 0, ctx->pinned[2 * PMC_MAX_GROUPS + g] = 0;
     if (int rc = drive()) return abandon(rc);
     // the end of the segment (a failure here leaves the segment abandoned like one in the generations)
     auto finish = [&]() -> int {
-        // (the last radiation-field logs of the groups are reduced on their streams)
-        if (rfLogged)
+        // what is left in the groups' statistics logs: the fills that came back with the groups' last generations are final (drive() has
+        // waited for every group); the groups' flushes run side by side on their streams
+        if (statLogged)
+            for (int g = 0; g < G; ++g)
+                if (int rc = statFlush(g, ctx->pinned[2 * PMC_MAX_GROUPS + g], ctx->groupStream[g])) return rc;
+        // (the last radiation-field logs of the groups are reduced on their streams too)
+        if (rfLogged || statLogged)
             for (int g = 0; g < G; ++g) HIP_TRY(hipStreamSynchronize(ctx->groupStream[g]));
-        // the segment's statistics: accumulator records -> wifu arrays (every group's stream has been waited for)
+        // the segment's statistics: accumulator records -> wifu arrays
         if (D.stat_acc_records) HIP_TRY(pmcLaunchStatMerge(ctx->slot, ctx->numCU * 8, st));
         HIP_TRY(hipEventRecord(ctx->evStop, st));
         HIP_TRY(hipEventSynchronize(ctx->evStop));
@@ -1692,10 +1857,21 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     ctx->transitionMs = transMs;
     ctx->peelMs = peelMs;
     ctx->propMs = propMs;
-    if (serialWalks && getenv("PMC_TIMING_DUMP"))
+    if (serialWalks && pmcTune("PMC_TIMING_DUMP"))
         fprintf(stderr, "PMC_TIMING peel %.2f ms prop %.2f ms transition+launch %.2f ms segment %.2f ms\n", peelMs, propMs, transMs, ctx->totalMs);
     ctx->generations = generations;
     ctx->timed = true;
+    // internal errors counted by the kernels (a sorted peel-off record without a place: see peelTile, pmc_transition.inc)
+    {
+        unsigned long long tail[3] = {0, 0, 0};  // counters 5 .. 7
+        HIP_TRY(hipMemcpy(tail, ctr + 5, sizeof(tail), hipMemcpyDeviceToHost));
+        if (tail[2] > ctx->internalErrorsSeen)
+        {
+            const unsigned long long fresh = tail[2] - ctx->internalErrorsSeen;
+            ctx->internalErrorsSeen = tail[2];
+            return fail(PMC_ERR_DEVICE, std::to_string(fresh) + " peel-off walks found no place in the sorted records (the two passes of the sort disagree): the segment's results are incomplete");
+        }
+    }
     // a history with more distinct pixels than the statistics list holds: the statistics arrays are wrong -- say so
     if (D.any_stats)
     {
@@ -1848,7 +2024,7 @@ int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out)
     out->scatterings = host[4];
     out->stat_overflows = host[5];
     out->rewalk_visits = host[6];
-    if (getenv("PMC_PROFILE_DUMP"))
+    if (pmcTune("PMC_PROFILE_DUMP"))
     {
         // work counters of the octree walk kernels: lane utilisation = lane_steps / (64 wave_steps)
         const unsigned long long* w = host + PMC_CTR_WALKWORK;
@@ -1858,7 +2034,7 @@ int pmc_counters(pmc_ctx* ctx, pmc_counter_values* out)
                 w[3] ? 100. * double(w[4]) / (64. * double(w[3])) : 0., w[5]);
     }
 #ifdef PMC_PROFILE
-    if (getenv("PMC_PROFILE_DUMP"))
+    if (pmcTune("PMC_PROFILE_DUMP"))
     {
         for (int k = 0; k < 2; ++k)
         {
@@ -1888,6 +2064,7 @@ int pmc_reset_counters(pmc_ctx* ctx)
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemsetAsync(ctx->dev.counters, 0, PMC_NUM_COUNTERS * sizeof(unsigned long long), ctx->stream));
     ctx->overflowsSeen = 0;
+    ctx->internalErrorsSeen = 0;
     return PMC_OK;
 }
 

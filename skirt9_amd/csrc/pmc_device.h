@@ -327,7 +327,7 @@ struct DevScene
     int32_t* stat_pool_free;
     int32_t  stat_pool_first[4];
     int32_t  stat_pool_count[4];
-    unsigned long long* counters;  // [PMC_NUM_COUNTERS]: [0..6] pmc_counter_values, [8] next history offset,
+    unsigned long long* counters;  // [PMC_NUM_COUNTERS]: [0..6] pmc_counter_values, [7] internal errors (pmc_run_primary fails), [8] next history offset,
                                    // [16..21] walk work, [32 + 4 g ..] work counters of slot group g, [120 + g] history bases,
                                    // [128 + 16 g ..] task cursors (PMC_CTR_*), [192..239] section timers of profiling builds
     SlotArrays slots;
@@ -354,6 +354,31 @@ struct RfLogArgs
     int32_t cursor;          // index of the log's cursor in DevScene::counters
     uint32_t padKey;         // key of the entries that fill up a wave's last chunk (beyond every table index)
 };
+// Statistics (FluxRecorder::recordContributions, FluxRecorder.cpp:962-1014): when a history ends, every entry of its contribution list --
+// (bin, summed weight w) -- adds w^0 .. w^4 to the bin's record of DevScene::stat_acc.  As atomics these are one sector request per
+// entry (3.7 per history on configs[1]: 33 ms of the launch kernel per 1e8 packets at the chip's 2.4e10 sector atomics/s); instead
+// the launch kernel (and the transition kernel of a sparse generation) appends the entries to a log per slot group -- key = record
+// index, value = w -- in chunks of PMC_RF_LOG_CHUNK entries that a WAVE claims from the log's cursor and keeps over the generations
+// (its place in its open chunk is saved when the kernel ends, by wave index, and taken up again by the next launch: a claim per
+// entry, or per wave and call, is a same-address atomic -- measured: the launch kernel twice as slow); chunkFill[chunk] tells the
+// flush how many entries of a chunk are there.  The log is partitioned by key range (the counting sort of the radiation-field log,
+// pmc_walk_tree.inc) and summed per bin in LDS (statReduceKernel) at the end of the segment, or when it is half full: 28 bytes of
+// streaming traffic per entry instead of a sector atomic, and no kernel more in the chain of a generation (every small kernel there
+// waits for a free CU next to the other groups' walk kernels: flushed every few generations the log was SLOWER than the atomics).
+struct StatLogArgs
+{
+    uint32_t* keys;
+    double* vals;
+    unsigned long long cap;        // entries; 0: no log, the sums are added atomically
+    int cursor;                    // index of the log's cursor in DevScene::counters
+    unsigned long long* waveBase;  // [PMC_STAT_LOG_WAVES] first entry of the open chunk of wave w of the kernels' grids
+    uint32_t* waveFill;            // [PMC_STAT_LOG_WAVES] entries of it in use (PMC_STAT_NO_CHUNK: the wave holds no chunk)
+    uint32_t* chunkFill;           // [cap / PMC_RF_LOG_CHUNK] entries of every chunk (PMC_RF_LOG_CHUNK unless a wave has left it open or short)
+};
+#define PMC_STAT_NO_CHUNK 0xFFFFFFFFu
+#define PMC_STAT_LOG_WAVES 16384  // waves of a launch / transition kernel grid that keep a chunk (1024 workgroups of four waves; beyond: atomics)
+#define PMC_STAT_BUCKET_BITS 11  // records per partition of the statistics log: 2^11 x five sums = 80 KB of LDS in statReduceKernel
+
 // Octree, up to PMC_SORT_OBS observers: the peel-off walks of a generation towards an observer as 64-byte records SORTED by the tile of the detector plane their start
 // position projects to: a counting sort on the tile in which the cycle start kernel is the scatter pass.  peelSortCountKernel counts the
 // slots that will have a walk per tile (from the slot's mode word and position), workgroup by workgroup; the cycle start kernel -- same
@@ -381,6 +406,7 @@ struct PeelSortArgs  // sort-count kernel and cycle start kernel; numObs == 0: n
     uint32_t* matrix[PMC_SORT_OBS];             // [workgroups][numParts]: entries of workgroup b's sort tiles per partition, then their prefix over the workgroups
     const unsigned long long* start[PMC_SORT_OBS];  // [numParts + 1] first record of every partition (start[numParts] = number of records)
     uint32_t numParts;                          // PMC_PEEL_TILES^2
+    uint32_t cap;                               // records (list entries) allocated per observer: a place beyond it is refused and counted (counters[7])
     int32_t ldsOffset;                          // cycle start kernel: where its cursors live in LDS (behind the grid tables): numObs x numParts
     double centre[3];                           // of the grid
     double scale;                               // PMC_PEEL_TILES / the grid's diagonal
@@ -424,6 +450,8 @@ struct PeelSortedArgs  // peel-off kernel; rec == nullptr: task records from Tas
 #define PMC_CTR_TASKS_PER_GROUP 32
 #define PMC_CTR_LIST(g) PMC_CTR_TASK(g, 30)        // entries of the group's list of live slots (TaskArrays::liveList)
 #define PMC_CTR_RFLOG(g) PMC_CTR_TASK(g, 31)       // entries of the group's radiation-field log claimed so far
+#define PMC_CTR_STATLOG(g) (56 + (g))              // entries of the group's statistics log claimed so far (kept over the generations: the log is
+                                                   // flushed when it has filled up, pmc_api.hip)
 // per slot group g: offset of the first history the group's ended slots take up this generation (endedScanKernel)
 #define PMC_CTR_HBASE(g) (120 + (g))
 #define PMC_MAX_GROUPS 4

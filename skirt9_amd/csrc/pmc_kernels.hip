@@ -143,6 +143,18 @@ static_assert(PMC_TRANSITION_BLOCK <= 256 && PMC_TRANSITION_BLOCK % 64 == 0,
                                 // 623 ms per 1e8 packets, profiles/sweeps/r03_batch32_sweep.txt, r03_batch33_sweep.txt)
 #endif
 
+// Builds with an ablation / perturbation / experiment macro (tuning aids: they change results or add work) identify themselves:
+// pmc_create prints a warning for such a library (pmc_api.hip)
+#if defined(PMC_ABLATE_REFINE) || defined(PMC_ABLATE_SLOW) || defined(PMC_ABLATE_RF_MATH) || defined(PMC_ABLATE_RF_LOG) || defined(PMC_ABLATE_FRAMEADD)      \
+    || defined(PMC_ABLATE_HOTBINS) || defined(PMC_ABLATE_DETECT) || defined(PMC_ABLATE_STATS) || defined(PMC_ABLATE_LAUNCH_DUST)                             \
+    || defined(PMC_ABLATE_LAUNCH_BINS) || defined(PMC_ABLATE_LAUNCH_FLUSH) || defined(PMC_EXPERIMENT_FOLD_OCTANT) || defined(PMC_PERTURB_VALU)               \
+    || defined(PMC_PERTURB_GATHER) || defined(PMC_PERTURB_LDS)
+extern "C" int pmcExperimentBuild(void) { return 1; }
+#else
+extern "C" int pmcExperimentBuild(void) { return 0; }
+#endif
+extern "C" const char* pmcTune(const char* name);  // tuning switches (pmc_api.hip, include/pmc_tuning.h)
+
 // the scene of every live context, in constant memory: all accesses are scalar loads
 __constant__ DevScene c_scene[PMC_MAX_CONTEXTS];
 
@@ -266,8 +278,13 @@ extern "C" hipError_t pmcConfigureKernels(size_t walkLds, size_t transitionLds)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfReduceKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)(sizeof(double) << PMC_RF_BUCKET_BITS));
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfScatterKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(size_t(RF_TILE) * (sizeof(double) + sizeof(uint32_t)) + size_t(2) * RF_MAX_PARTS * sizeof(uint32_t)));
+        const int scatterLds = (int)(size_t(RF_TILE) * (sizeof(double) + sizeof(uint32_t)) + size_t(2) * RF_MAX_PARTS * sizeof(uint32_t));
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfScatterKernel<PMC_RF_BUCKET_BITS>), hipFuncAttributeMaxDynamicSharedMemorySize, scatterLds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rfScatterKernel<PMC_STAT_BUCKET_BITS>), hipFuncAttributeMaxDynamicSharedMemorySize, scatterLds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&statReduceKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(5 * sizeof(double) << PMC_STAT_BUCKET_BITS));
         if (e != hipSuccess) return e;
     }
     const struct
@@ -349,7 +366,7 @@ extern "C" int pmcWalkBlocksPerCU(int gridKind, int kind, int wide, int block, s
     {
         // (with the pass-1 checkpoints of pmcLaunchProp)
         const size_t trimOffset = (ldsBytes + 15) & ~size_t(15);
-        if (!getenv("PMC_PROP_NO_TRIM") && trimOffset + PROP_CKPT_BYTES <= size_t(160) * 1024) ldsBytes = trimOffset + PROP_CKPT_BYTES;
+        if (!pmcTune("PMC_PROP_NO_CHECKPOINTS") && trimOffset + PROP_CKPT_BYTES <= size_t(160) * 1024) ldsBytes = trimOffset + PROP_CKPT_BYTES;
         e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<true, false, false, false>), block, ldsBytes)
                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(&walkPropKernel<false, false, false, false>), block, ldsBytes);
     }
@@ -398,7 +415,7 @@ extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int tas
 // does the peel-off kernel of this octree run with task queues (the form that can take sorted records)?
 extern "C" int pmcPeelHasQueues(int wide, size_t ldsBytes)
 {
-    static const bool first = getenv("PMC_PEEL_V1") != nullptr;
+    const bool first = pmcTune("PMC_PEEL_V1") != nullptr;
     return !first && (wide & 2) == 0 && ((ldsBytes + 15) & ~size_t(15)) + pmcPeelQueueBytes() <= size_t(160) * 1024;
 }
 // sorted peel-off records (pmc_device.h PeelRec): the count pass of the sort over the slots of a group, behind its transition / launch kernels; the
@@ -440,7 +457,7 @@ extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlo
 extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int sgn, int grid, size_t ldsBytes,
                                     const PeelRec* sortedRec, const unsigned long long* sortedCount, unsigned long long* xcdCursor, hipStream_t stream)
 {
-    static const bool first = getenv("PMC_PEEL_V1") != nullptr;  // (tuning aid: the form with service rounds)
+    const bool first = pmcTune("PMC_PEEL_V1") != nullptr;  // (tuning aid: the form with service rounds)
     // (`wide` bit 1: several medium components -- the form with service rounds)
     const bool mm = (wide & 2) != 0;
     wide &= 1;
@@ -479,7 +496,7 @@ extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBas
                                     walkPropKernel<true, false, true, true>,   walkPropKernel<true, true, true, true>};
     const Kernel kernel = wide ? wider[storeRf & 7] : narrow[storeRf & 7];
     // (the pass-1 checkpoints follow the grid tables in LDS, if there is room)
-    static const bool noTrim = getenv("PMC_PROP_NO_TRIM") != nullptr;  // (tuning aid)
+    const bool noTrim = pmcTune("PMC_PROP_NO_CHECKPOINTS") != nullptr;  // (tuning aid: pass 2 walks every path from its start)
     const size_t trimOffset = (ldsBytes + 15) & ~size_t(15);
     const bool trim = !noTrim && !ea && !mm && trimOffset + PROP_CKPT_BYTES <= size_t(160) * 1024;
     RfLogArgs none = {nullptr, nullptr, 0ull, 0, 0u};
@@ -494,8 +511,9 @@ extern "C" size_t pmcRfTempBytes(int numParts) { return (size_t(2) * size_t(numP
 extern "C" int pmcRfMaxParts() { return (int)RF_MAX_PARTS; }
 // the counting sort of (key, value) pairs on key >> PMC_RF_BUCKET_BITS: n entries in whole tiles of RF_TILE -> (sortedKeys, sortedVals), pad
 // keys dropped; temp = 2 * numParts + 1 counters: the partition starts are left at temp + numParts (numParts + 1 of them)
+template<int BITS>
 static hipError_t launchPartition(const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n, int numParts,
-                                  void* temp, int numCU, hipStream_t stream)
+                                  void* temp, int numCU, hipStream_t stream, const uint32_t* fills = nullptr)
 {
     unsigned long long* cursor = static_cast<unsigned long long*>(temp);
     unsigned long long* start = cursor + numParts;
@@ -503,23 +521,37 @@ static hipError_t launchPartition(const uint32_t* keys, const double* vals, uint
     if (e != hipSuccess) return e;
     const unsigned long long tiles = n / RF_TILE;
     const unsigned grid = (unsigned)std::min<unsigned long long>(tiles, (unsigned long long)numCU * 8ull);
-    hipLaunchKernelGGL(rfHistKernel, dim3(std::max(grid, 1u)), dim3(256), 0, stream, keys, n, (uint32_t)numParts, cursor);
+    hipLaunchKernelGGL(rfHistKernel<BITS>, dim3(std::max(grid, 1u)), dim3(256), 0, stream, keys, n, (uint32_t)numParts, cursor, fills);
     hipLaunchKernelGGL(rfScanKernel, dim3(1), dim3(1024), 0, stream, cursor, start, (uint32_t)numParts);
     const size_t sortLds = size_t(RF_TILE) * (sizeof(double) + sizeof(uint32_t)) + size_t(2) * size_t(numParts) * sizeof(uint32_t);
     const unsigned sortGrid = (unsigned)std::min<unsigned long long>(tiles, (unsigned long long)numCU * 3ull);
-    hipLaunchKernelGGL(rfScatterKernel, dim3(std::max(sortGrid, 1u)), dim3(RF_SORT_BLOCK), sortLds, stream, keys, vals, n, (uint32_t)numParts, cursor, sortedKeys,
-                       sortedVals);
+    hipLaunchKernelGGL(rfScatterKernel<BITS>, dim3(std::max(sortGrid, 1u)), dim3(RF_SORT_BLOCK), sortLds, stream, keys, vals, n, (uint32_t)numParts, cursor, sortedKeys,
+                       sortedVals, fills);
     return hipGetLastError();
 }
 extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n,
                                        int numParts, void* temp, int numCU, hipStream_t stream)
 {
-    hipError_t e = launchPartition(keys, vals, sortedKeys, sortedVals, n, numParts, temp, numCU, stream);
+    hipError_t e = launchPartition<PMC_RF_BUCKET_BITS>(keys, vals, sortedKeys, sortedVals, n, numParts, temp, numCU, stream);
     if (e != hipSuccess) return e;
     const unsigned long long* start = static_cast<const unsigned long long*>(temp) + numParts;
     const size_t lds = sizeof(double) << PMC_RF_BUCKET_BITS;  // (the limit is raised per device in pmcConfigureKernels)
     const unsigned long long blocks = (n + PMC_RF_REDUCE_SPAN - 1) / PMC_RF_REDUCE_SPAN;
     hipLaunchKernelGGL(rfReduceKernel, dim3((unsigned)blocks), dim3(RF_REDUCE_BLOCK), lds, stream, slot, sortedKeys, sortedVals, start, (uint32_t)numParts);
+    return hipGetLastError();
+}
+// statistics: the log of a slot group (n entries in whole chunks) partitioned by record range into (sortedKeys, sortedVals) and summed into the
+// accumulator records; temp = 2 * numParts + 1 counters (pmcRfTempBytes)
+extern "C" int pmcStatBucketBits() { return PMC_STAT_BUCKET_BITS; }
+extern "C" hipError_t pmcLaunchStatFlush(int slot, const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n,
+                                         int numParts, void* temp, int numCU, const uint32_t* chunkFill, hipStream_t stream)
+{
+    hipError_t e = launchPartition<PMC_STAT_BUCKET_BITS>(keys, vals, sortedKeys, sortedVals, n, numParts, temp, numCU, stream, chunkFill);
+    if (e != hipSuccess) return e;
+    const unsigned long long* start = static_cast<const unsigned long long*>(temp) + numParts;
+    const size_t lds = 5 * sizeof(double) << PMC_STAT_BUCKET_BITS;
+    const unsigned long long blocks = (n + PMC_RF_REDUCE_SPAN - 1) / PMC_RF_REDUCE_SPAN;
+    hipLaunchKernelGGL(statReduceKernel, dim3((unsigned)blocks), dim3(RF_REDUCE_BLOCK), lds, stream, slot, sortedKeys, sortedVals, start, (uint32_t)numParts);
     return hipGetLastError();
 }
 // end of a segment: statistics accumulator -> wifu arrays of the frames
@@ -532,12 +564,13 @@ extern "C" hipError_t pmcLaunchStatMerge(int slot, int blocks, hipStream_t strea
 // transitions of the slots [slotBase, slotBase + numSlots) of slot group `group`, followed by the scan of the group's
 // ended-history counts (the launch kernel's history indices)
 extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, const int* list, int listLen, int maxBlocks,
-                                          size_t ldsBytes, hipStream_t stream)
+                                          size_t ldsBytes, const StatLogArgs* statLog, hipStream_t stream)
 {
+    const StatLogArgs none = {nullptr, nullptr, 0ull, 0, nullptr, nullptr, nullptr};
     const int block = PMC_TRANSITION_BLOCK;
     // (a sparse generation: one list entry per lane; otherwise persistent workgroups over runs of 256 slots per wave)
     const int grid = std::max(1, std::min(((list ? listLen : numSlots) + block - 1) / block, maxBlocks));
-    hipLaunchKernelGGL(transitionKernel, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group, seed, list, listLen);
+    hipLaunchKernelGGL(transitionKernel, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group, seed, list, listLen, statLog ? *statLog : none);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || list) return e;  // (a sparse generation retires its ended histories in the transition kernel)
     hipLaunchKernelGGL(endedScanKernel, dim3(1), dim3(1024), 0, stream, slot, slotBase, numSlots, group);
@@ -546,10 +579,11 @@ extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, 
 
 // launches of new histories into the slots of the group whose history ended (initial: into all slots of the group)
 extern "C" hipError_t pmcLaunchLaunch(int slot, int slotBase, int numSlots, int group, uint64_t first, uint64_t count, uint64_t seed, int initial,
-                                      int maxBlocks, size_t ldsBytes, hipStream_t stream)
+                                      int maxBlocks, size_t ldsBytes, const StatLogArgs* statLog, hipStream_t stream)
 {
+    const StatLogArgs none = {nullptr, nullptr, 0ull, 0, nullptr, nullptr, nullptr};
     const int grid = std::max(1, std::min((numSlots + 255) / 256, maxBlocks));
-    hipLaunchKernelGGL(launchKernel, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, first, count, seed, initial);
+    hipLaunchKernelGGL(launchKernel, dim3(grid), dim3(256), ldsBytes, stream, slot, slotBase, numSlots, group, first, count, seed, initial, statLog ? *statLog : none);
     return hipGetLastError();
 }
 

@@ -14,7 +14,7 @@ from .host import CounterValues, FrameLayout
 
 _LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 
-# every symbol include/pmc.h declares
+# every symbol include/pmc.h and include/pmc_tuning.h declare
 SYMBOLS = ["pmc_abi_version", "pmc_last_error", "pmc_frame_layout_of", "pmc_create", "pmc_destroy", "pmc_bind_frames",
            "pmc_clear_frames", "pmc_run_primary", "pmc_sync", "pmc_download", "pmc_frames_device", "pmc_frames_size",
            "pmc_last_kernel_ms", "pmc_counters", "pmc_reset_counters", "pmc_trace_ray", "pmc_set_launch",
@@ -22,18 +22,18 @@ SYMBOLS = ["pmc_abi_version", "pmc_last_error", "pmc_frame_layout_of", "pmc_crea
            "pmc_download_radiation_field", "pmc_clear_radiation_field", "pmc_bind_radiation_field", "pmc_sampler_create",
            "pmc_sampler_density", "pmc_sampler_destroy", "pmc_history_range", "pmc_comm_init_all", "pmc_comm_unique_id",
            "pmc_comm_init_rank", "pmc_comm_size", "pmc_comm_destroy", "pmc_reduce_frames", "pmc_allreduce_radiation_field",
-           "pmc_debug_tables"]
+           "pmc_debug_tables", "pmc_tuning_set", "pmc_tuning_clear"]
 
 _lib = None
 
 
 class DebugTables(C.Structure):
-    """pmc_debug_table_values (include/pmc.h): device addresses for profiles/microbench/bridge.hip"""
+    """pmc_debug_table_values (include/pmc_tuning.h): device addresses for profiles/microbench/bridge.hip"""
     _fields_ = [("cell_table", C.c_void_p), ("cell_slots", C.c_int64), ("loose_base", C.c_int64), ("task_cell", C.c_void_p), ("num_slots", C.c_int64)]
 
 
 class WalkWork(C.Structure):
-    """pmc_walk_work_values (include/pmc.h)"""
+    """pmc_walk_work_values (include/pmc_tuning.h)"""
     _fields_ = [(n, C.c_uint64) for n in ("peel_wave_steps", "peel_lane_steps", "peel_rounds", "prop_wave_steps",
                                           "prop_lane_steps", "prop_rounds")]
 
@@ -91,8 +91,41 @@ def lib():
         L.pmc_comm_destroy.argtypes = [C.c_void_p]
         L.pmc_reduce_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.pmc_allreduce_radiation_field.argtypes = [C.c_void_p, C.c_void_p]
+        if hasattr(L, "pmc_tuning_set"):
+            L.pmc_tuning_set.argtypes = [C.c_char_p, C.c_char_p]
+            L.pmc_tuning_clear.restype = None
         _lib = L
     return _lib
+
+
+# settings the library itself reads from the environment (include/pmc.h); every other PMC_* name is a tuning switch
+ENVIRONMENT_SETTINGS = ("PMC_NUM_SLOTS", "PMC_NUM_GROUPS", "PMC_STAT_POOL_BLOCKS")
+
+
+def set_tuning(name, value="1"):
+    """a tuning switch of the engine (include/pmc_tuning.h pmc_tuning_set): alternative code paths for cross-checks and A/B
+    timing; value None removes it.  (Engines built before the switch table existed read the same names from the environment.)"""
+    L = lib()
+    if hasattr(L, "pmc_tuning_set"):
+        _check(L.pmc_tuning_set(name.encode(), None if value is None else str(value).encode()))
+    elif value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+
+
+def clear_tuning():
+    L = lib()
+    if hasattr(L, "pmc_tuning_clear"):
+        L.pmc_tuning_clear()
+
+
+def tuning_from_environment():
+    """tools only (bench.py, tools/sweep.py): hands the PMC_* variables of the environment that are not library settings to the
+    engine as tuning switches -- the library itself does not read them"""
+    for key, value in os.environ.items():
+        if key.startswith("PMC_") and key not in ENVIRONMENT_SETTINGS and key != "PMC_LIBRARY":
+            set_tuning(key, value)
 
 
 def _check(rc):

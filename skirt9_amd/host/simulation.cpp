@@ -190,10 +190,16 @@ namespace skh
         }
 
         std::string mode = sim.attr("simulationMode", "ExtinctionOnly");
+        // (the modes without a medium: Configuration::hasMedium() is false, the medium system of the ski file -- if any -- is not
+        // relevant, and the photon life cycle ends with the emission peel-off, MonteCarloSimulation.cpp:557)
         if (mode == "OligoExtinctionOnly")
             _oligo = true;
         else if (mode == "ExtinctionOnly")
             _oligo = false;
+        else if (mode == "OligoNoMedium")
+            _oligo = true, _hasMedium = false;
+        else if (mode == "NoMedium")
+            _oligo = false, _hasMedium = false;
         else
             unsupported("simulationMode " + mode);
         if (rd.boolean(sim, "iteratePrimaryEmission", false)) unsupported("iteratePrimaryEmission");
@@ -383,8 +389,32 @@ namespace skh
         }  // sources
 
         // ---- medium system
-        const XmlElement* ms = sim.item("mediumSystem");
-        if (!ms) unsupported("a simulation without a medium system");
+        const XmlElement* ms = _hasMedium ? sim.item("mediumSystem") : nullptr;
+        if (_hasMedium && !ms) throw std::runtime_error("ski: simulationMode " + mode + " needs a medium system");
+        if (!ms)
+        {
+            // A simulation without a medium (MonteCarloSimulation.cpp:557; FluxRecorder.cpp:199: the total flux only).  The engine's
+            // life cycle is that of a medium system whose one cell holds no matter: the emission peel-off sees optical depth zero, the
+            // path of the packet has optical depth zero, and the history ends (MonteCarloSimulation.cpp:705-709).  One density sample
+            // at the cell centre: the setup draws no random number, as the reference's setup without a medium draws none.
+            static const char* const standIn =
+                "<mediumSystem type=\"MediumSystem\"><MediumSystem>"
+                "<photonPacketOptions type=\"PhotonPacketOptions\"><PhotonPacketOptions explicitAbsorption=\"false\" forceScattering=\"true\" "
+                "minWeightReduction=\"1e4\" minScattEvents=\"0\" pathLengthBias=\"0.5\"/></photonPacketOptions>"
+                "<media type=\"Medium\"><GeometricMedium>"
+                "<geometry type=\"Geometry\"><UniformBoxGeometry minX=\"-1 m\" maxX=\"1 m\" minY=\"-1 m\" maxY=\"1 m\" minZ=\"-1 m\" maxZ=\"1 m\"/></geometry>"
+                "<materialMix type=\"MaterialMix\"><MeanListDustMix wavelengths=\"1e-6 micron, 1e6 micron\" extinctionCoefficients=\"1 m2/kg, 1 m2/kg\" "
+                "albedos=\"0.5, 0.5\" asymmetryParameters=\"0, 0\"/></materialMix>"
+                "<normalization type=\"MaterialNormalization\"><NumberMaterialNormalization number=\"0\"/></normalization>"
+                "</GeometricMedium></media>"
+                "<samplingOptions type=\"SamplingOptions\"><SamplingOptions numDensitySamples=\"1\"/></samplingOptions>"
+                "<grid type=\"SpatialGrid\"><CartesianSpatialGrid minX=\"-1 m\" maxX=\"1 m\" minY=\"-1 m\" maxY=\"1 m\" minZ=\"-1 m\" maxZ=\"1 m\">"
+                "<meshX type=\"Mesh\"><LinMesh numBins=\"1\"/></meshX><meshY type=\"Mesh\"><LinMesh numBins=\"1\"/></meshY>"
+                "<meshZ type=\"Mesh\"><LinMesh numBins=\"1\"/></meshZ></CartesianSpatialGrid></grid>"
+                "</MediumSystem></mediumSystem>";
+            _standInMediumSystem = XmlParser(standIn).parseDocument();
+            ms = _standInMediumSystem->children.front().get();
+        }
         _options.force_scattering = 1;
         _options.min_weight_reduction = 1e4;
         _options.min_scatt_events = 0;
@@ -1095,8 +1125,9 @@ namespace skh
                 p.xpsiz = p.ypsiz = 0.5 * DBL_MAX;
             }
             p.aperture_radius2 = ins.radius * ins.radius;
-            p.record_components = ins.recordComponents;  // a medium is always present on this path
-            p.num_scattering_levels = ins.recordComponents ? ins.numScatteringLevels : 0;
+            // (FluxRecorder.cpp:199: without a medium the total flux is all there is to record)
+            p.record_components = ins.recordComponents && _hasMedium;
+            p.num_scattering_levels = p.record_components ? ins.numScatteringLevels : 0;
             p.record_statistics = ins.recordStatistics;
             p.redshift = ins.redshift;
             p.num_lambda = ins.grid->numBins();

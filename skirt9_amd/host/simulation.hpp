@@ -88,6 +88,8 @@ namespace skh
         // medium system
         pmc_options _options{};
         int _numDensitySamples{100};
+        bool _hasMedium{true};                              // Configuration::hasMedium(): false in the NoMedium simulation modes
+        std::unique_ptr<XmlElement> _standInMediumSystem;   // (those modes: the empty one-cell medium system the engine runs with)
         std::vector<std::unique_ptr<Medium>> _media;   // the medium components, in ski order (MediumSystem::_media)
         CompositeMedium _composite;                    // all of them as one dust distribution (grid setup)
         Medium* _medium{nullptr};                      // the only component, or the composite

@@ -28,3 +28,12 @@ def ski(name):
 
 def golden(name):
     return os.path.join(ROOT, "tests", "golden", name)
+
+
+@pytest.fixture(autouse=True)
+def _no_tuning_left_behind():
+    """the engine's tuning switches (include/pmc_tuning.h) are process-wide: whatever a test sets is gone before the next one"""
+    yield
+    engine = sys.modules.get("skirt9_amd.engine")
+    if engine is not None and engine._lib is not None:
+        engine.clear_tuning()

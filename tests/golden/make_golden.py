@@ -30,6 +30,8 @@ Fixtures:
                678-730, 796-817): reduced config 2 with a second dust component (Plummer sphere, other mix, mass normalisation), the same
                with explicit absorption, the non-forced variant of config 1 with THREE components, reduced config 3 (panchromatic) with two,
                and config 1 with three components and the radiation field stored
+  cfg1nomed_*  a simulation WITHOUT a medium system (simulationMode OligoNoMedium; MonteCarloSimulation.cpp:557: emission peel-off only,
+               FluxRecorder records the total flux only): the point source of config 1, 10^5 packets -> files
   cfg5small_*  reduced config 5 (tests/ski/cfg5small.ski): Voronoi grid with 1500 random sites, panchromatic, four
                instruments -> files, rays, cells (the host layer's tessellation is its own: the traversal is compared bit
                for bit, cell volumes to rounding, sampled densities and output files statistically)
@@ -139,7 +141,7 @@ def main():
     if not os.path.exists(REF):
         sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
     for name, scale in (("cfg1", 3.08567758e16), ("cfg1mesh", 3.08567758e16), ("cfg1mesh2", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg2deep", 300 * 3.08567758e16), ("cfg2deeper", 100 * 3.08567758e16), ("cfg3small", None), ("cfg3z", None), ("cfg1nf", None), ("cfg2nf", None),
-                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1sed", None), ("cfg3sed", None), ("cfg3norm", "sed"), ("cfg3disk", "sed"), ("cfg3multi", "sed"), ("cfg3ten", "sed"), ("cfg3flat", "sed"), ("cfg3off", "sed"), ("cfg3plum", "sed"), ("cfg1rf", "rf"), ("cfg3rf", "rf"), ("cfg2ea", None), ("cfg1nfea", None), ("cfg1rfea", "rf"), ("cfg2mm", None), ("cfg2mmea", None), ("cfg1mmnf", None), ("cfg3mm", None), ("cfg1mmrf", "rf"), ("cfg1con", None), ("cfg1netzer", None), ("cfg1laser", None), ("cfg2agn", None),
+                        ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1sed", None), ("cfg3sed", None), ("cfg3norm", "sed"), ("cfg3disk", "sed"), ("cfg3multi", "sed"), ("cfg3ten", "sed"), ("cfg3flat", "sed"), ("cfg3off", "sed"), ("cfg3plum", "sed"), ("cfg1rf", "rf"), ("cfg3rf", "rf"), ("cfg2ea", None), ("cfg1nfea", None), ("cfg1rfea", "rf"), ("cfg2mm", None), ("cfg2mmea", None), ("cfg1mmnf", None), ("cfg3mm", None), ("cfg1mmrf", "rf"), ("cfg1con", None), ("cfg1netzer", None), ("cfg1laser", None), ("cfg2agn", None), ("cfg1nomed", None),
                         ("cfg5small", 4000 * 3.08567758e16), ("cfg5dd", "cells"), ("cfg2shell", "cells"), ("cfg2torus", "cells"), ("cfg2ring", "cells"), ("cfg1list", "cells")):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue

@@ -21,13 +21,38 @@ def libpmc():
 
 
 def test_every_declared_symbol_is_exported(libpmc):
-    header = open(os.path.join(ROOT, "include", "pmc.h")).read()
-    declared = sorted(set(re.findall(r"\b(pmc_[a-z_]+)\s*\(", header)))
+    """the drop-in boundary (include/pmc.h) and the tuning aids (include/pmc_tuning.h: a header of its own, nothing a caller needs)"""
+    boundary = open(os.path.join(ROOT, "include", "pmc.h")).read()
+    tuning = open(os.path.join(ROOT, "include", "pmc_tuning.h")).read()
+    declared = sorted(set(re.findall(r"\b(pmc_[a-z_]+)\s*\(", boundary + tuning)))
     from skirt9_amd import engine
     assert sorted(engine.SYMBOLS) == declared
     for name in declared:
         assert hasattr(libpmc, name), name
     assert libpmc.pmc_abi_version() == 9
+    # the boundary header declares no tuning entry
+    for name in ("pmc_tuning_set", "pmc_set_launch", "pmc_debug_tables", "pmc_walk_work"):
+        assert name not in boundary and name in tuning
+
+
+def test_the_library_reads_three_environment_settings_only():
+    """experiment switches go through pmc_tuning_set (include/pmc_tuning.h), not through the environment of the process"""
+    names = set()
+    for f in os.listdir(os.path.join(ROOT, "skirt9_amd", "csrc")):
+        names |= set(re.findall(r'getenv\("([A-Z_0-9]+)"\)', open(os.path.join(ROOT, "skirt9_amd", "csrc", f)).read()))
+    assert names == {"PMC_NUM_SLOTS", "PMC_NUM_GROUPS", "PMC_STAT_POOL_BLOCKS"}
+
+
+def test_tuning_switch_table(libpmc):
+    from skirt9_amd import engine
+    engine.set_tuning("PMC_NO_LIVE_LISTS", "1")
+    libpmc.pmcTune.restype = C.c_char_p
+    assert libpmc.pmcTune(b"PMC_NO_LIVE_LISTS") == b"1"
+    engine.set_tuning("PMC_NO_LIVE_LISTS", None)
+    assert libpmc.pmcTune(b"PMC_NO_LIVE_LISTS") is None
+    engine.set_tuning("PMC_RF_LOG_PER_SLOT", 7)
+    engine.clear_tuning()
+    assert libpmc.pmcTune(b"PMC_RF_LOG_PER_SLOT") is None
 
 
 def test_history_range_is_the_library_function(libpmc):

@@ -19,6 +19,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+from skirt9_amd.engine import set_tuning
 from conftest import ski
 from skirt9_amd.host import Simulation
 
@@ -135,12 +136,12 @@ def test_full_size_three_slot_groups_refills_and_drain(full, monkeypatch):
         lists = eng.download()
         c = eng.counters()
         assert c["histories"] == n and c["stat_overflows"] == 0
-        monkeypatch.setenv("PMC_NO_LIVE_LISTS", "1")
+        set_tuning("PMC_NO_LIVE_LISTS", "1")
         eng.clear()
         eng.run_primary(0, n, 5)
         plain = eng.download()
     finally:
-        monkeypatch.delenv("PMC_NO_LIVE_LISTS", raising=False)
+        set_tuning("PMC_NO_LIVE_LISTS", None)
         eng.set_num_slots(8 * 1024 * 1024)
     nl, npix = lay.num_lambda, lay.npix
     w0 = slice(lay.wifu_offset, lay.wifu_offset + nl * npix)
@@ -276,7 +277,7 @@ def test_full_size_radiation_field_log_partition(tmp_path, monkeypatch):
     eng.run_primary(0, big, 22)
     logged = eng.download_radiation_field()
     eng.close()
-    monkeypatch.setenv("PMC_RF_ATOMICS", "1")
+    set_tuning("PMC_RF_ATOMICS", "1")
     eng = Engine(sim.scene, 0)
     eng.run_primary(0, big, 22)
     atomics = eng.download_radiation_field()
@@ -297,7 +298,7 @@ def test_full_size_sorted_peel_records_change_nothing(full, monkeypatch):
     eng.reset_counters()
     eng.run_primary(0, n, 31)
     a, ca = eng.download(), eng.counters()
-    monkeypatch.setenv("PMC_NO_PEEL_SORT", "1")
+    set_tuning("PMC_NO_PEEL_SORT", "1")
     plain = Engine(sim.scene, 0)
     plain.run_primary(0, n, 31)
     b, cb = plain.download(), plain.counters()
@@ -334,7 +335,7 @@ def test_full_size_sorted_peel_records_three_observers(tmp_path, monkeypatch):
     eng.close()
     ref, _ = O.run_primary(sim, 0, 20000, O.RNG_PHILOX, seed=6)
     _compare_frames(sim, small, ref, 20000)
-    monkeypatch.setenv("PMC_NO_PEEL_SORT", "1")
+    set_tuning("PMC_NO_PEEL_SORT", "1")
     plain = Engine(sim.scene, 0)
     plain.run_primary(0, n, 5)
     b_frames, cb = plain.download(), plain.counters()

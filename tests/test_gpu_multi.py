@@ -9,6 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
+from skirt9_amd.engine import set_tuning
 from conftest import ROOT, ski
 
 pytestmark = pytest.mark.gpu
@@ -145,9 +146,9 @@ def test_sparse_generations_equal_the_slot_order_generations(monkeypatch):
     out = []
     for lists in (True, False):
         if lists:
-            monkeypatch.delenv("PMC_NO_LIVE_LISTS", raising=False)
+            set_tuning("PMC_NO_LIVE_LISTS", None)
         else:
-            monkeypatch.setenv("PMC_NO_LIVE_LISTS", "1")
+            set_tuning("PMC_NO_LIVE_LISTS", "1")
         eng = Engine(sim.scene, 0)
         eng.run_primary(0, n // 3, 7)
         eng.run_primary(n // 3, n - n // 3, 7)
@@ -177,9 +178,9 @@ def test_one_wavelength_constants_equal_the_per_slot_arrays(monkeypatch):
         out = []
         for mono in (True, False):
             if mono:
-                monkeypatch.delenv("PMC_NO_MONO", raising=False)
+                set_tuning("PMC_NO_MONO", None)
             else:
-                monkeypatch.setenv("PMC_NO_MONO", "1")
+                set_tuning("PMC_NO_MONO", "1")
             eng = Engine(sim.scene, 0)
             eng.run_primary(0, n, 3)
             out.append((eng.download(), eng.counters()))

@@ -22,12 +22,13 @@ def _same_file(path_a, path_b):
     return a == b
 
 
-@pytest.mark.parametrize("name,nfiles", [("cfg1", 11), ("cfg1mesh", 11), ("cfg1mesh2", 11), ("cfg2small", 11), ("cfg2deep", 11), ("cfg2deeper", 11), ("cfg3small", 27), ("cfg3z", 35), ("cfg1nf", 12), ("cfg2nf", 11), ("cfg4small", 11), ("cfg1file", 11), ("cfg1sed", 14), ("cfg3sed", 27), ("cfg2ea", 11), ("cfg1nfea", 12), ("cfg2mm", 11), ("cfg2mmea", 11), ("cfg1mmnf", 12), ("cfg3mm", 27), ("cfg1con", 11), ("cfg1netzer", 11), ("cfg1laser", 11), ("cfg2agn", 11)])
+@pytest.mark.parametrize("name,nfiles", [("cfg1", 11), ("cfg1mesh", 11), ("cfg1mesh2", 11), ("cfg2small", 11), ("cfg2deep", 11), ("cfg2deeper", 11), ("cfg3small", 27), ("cfg3z", 35), ("cfg1nf", 12), ("cfg2nf", 11), ("cfg4small", 11), ("cfg1file", 11), ("cfg1sed", 14), ("cfg3sed", 27), ("cfg2ea", 11), ("cfg1nfea", 12), ("cfg2mm", 11), ("cfg2mmea", 11), ("cfg1mmnf", 12), ("cfg3mm", 27), ("cfg1con", 11), ("cfg1netzer", 11), ("cfg1laser", 11), ("cfg2agn", 11), ("cfg1nomed", 8)])
 def test_byte_identical_to_reference(name, nfiles, tmp_path):
     """cfg3small: panchromatic sampling with a wavelength bias, tabulated dust, 20 wavelength bins, and three
     instruments (scattering levels, a FrameInstrument sharing its observer, a second observer); cfg1nf: non-forced
     scattering, box source that sticks out of the grid, isotropic and strongly forward scattering dust; cfg3z: model
-    redshift 0.5 (FlatUniverseCosmology), six instruments, three of them in the observer frame"""
+    redshift 0.5 (FlatUniverseCosmology), six instruments, three of them in the observer frame; cfg1nomed: a simulation without a
+    medium system (total flux only)"""
     sim = Simulation(ski(name + ".ski")).setup()
     frames, counters = O.run_primary(sim, 0, sim.num_packets, O.RNG_MT19937)
     assert counters.histories == sim.num_packets

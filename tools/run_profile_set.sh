@@ -14,6 +14,9 @@ timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/benc
 (cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_FETCH_SIZE -- python $R/bench.py --steps 1 --warmup 0 --packets 2e7 --no-cpu-baseline --no-secondary --no-breakdown > $O/pmc_f.log 2>&1)
 (cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_WRITE_SIZE -- python $R/bench.py --steps 1 --warmup 0 --packets 2e7 --no-cpu-baseline --no-secondary --no-breakdown > $O/pmc_w.log 2>&1)
 python tools/pmc_hbm_summary.py $O > $O/pmc_hbm.csv; cat $O/pmc_hbm.csv
+# L2 requests / hits / misses and VALU instructions per kernel (a pass of its own): the line-rate evidence of bench.py's roofline.dominant_kernel
+(cd /tmp && timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/pmc_l2 -- python $R/bench.py --steps 1 --warmup 0 --packets 2e7 --no-cpu-baseline --no-secondary --no-breakdown > $O/pmc_l2.log 2>&1)
+python tools/pmc_l2_summary.py $O/pmc_l2 > $O/pmc_l2.csv; cat $O/pmc_l2.csv
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +8M -delete
 # the other workloads
 timeout 600 python bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_config3.json 2> $O/c3.err

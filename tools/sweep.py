@@ -37,6 +37,10 @@ def main():
             os.environ[k] = val
             keys.add(k)
         engine._lib = None
+        # (PMC_NUM_SLOTS / PMC_NUM_GROUPS / PMC_STAT_POOL_BLOCKS are library settings read from the environment; every other PMC_*
+        # pair is a tuning switch, include/pmc_tuning.h)
+        engine.clear_tuning()
+        engine.tuning_from_environment()
         eng = engine.Engine(sim.scene, 0)
         frames.zero_()
         eng.bind_frames(frames.data_ptr(), frames.numel())
