@@ -307,6 +307,12 @@ int pmc_clear_frames(pmc_ctx* ctx);
    during a segment are statistics lost: the call then returns PMC_ERR_OVERFLOW (the flux arrays are unaffected, the statistics
    arrays of the segment are incomplete, the next segment starts with a full pool). */
 int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed);
+/* Progress of a running segment (MonteCarloSimulation::logProgress, MonteCarloSimulation.cpp:522-526,609 -> Log::infoIfElapsed): while
+   pmc_run_primary drives its generations it calls `report(user, launched, count)` from the calling thread -- launched = histories of the
+   segment that SourceSystem has handed out so far -- at most once per `interval_seconds` (the reference logs every 3 s).  report == NULL
+   switches it off (the default). */
+typedef void (*pmc_progress_fn)(void* user, uint64_t launched, uint64_t count);
+int pmc_set_progress(pmc_ctx* ctx, pmc_progress_fn report, void* user, double interval_seconds);
 int pmc_sync(pmc_ctx* ctx);
 int pmc_download(pmc_ctx* ctx, double* host_frames, int64_t num_doubles);
 double* pmc_frames_device(pmc_ctx* ctx);
@@ -330,7 +336,7 @@ int pmc_reset_counters(pmc_ctx* ctx);
 /* Walk one ray on the device with the same traversal code the photon loop uses; k is normalised by the caller.
    Writes up to cap segments (cell index m or -1, length ds) and the number found to *n. */
 int pmc_trace_ray(pmc_ctx* ctx, const double r[3], const double k[3], int32_t* m, double* ds, int32_t cap, int32_t* n);
-/* number of photon histories kept in flight on the device (default 8 Mi; environment PMC_NUM_SLOTS).  The slots are
+/* number of photon histories kept in flight on the device (default 24 Mi, fewer where the device memory is short; environment PMC_NUM_SLOTS).  The slots are
    divided into slot groups (default 3; environment PMC_NUM_GROUPS) whose generations run on separate streams */
 int pmc_set_num_slots(pmc_ctx* ctx, int64_t num_slots);
 /* HIP-event timing of the most recent pmc_run_primary: whole segment, sum over its walk-kernel launches, sum over

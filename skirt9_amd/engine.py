@@ -16,7 +16,7 @@ _LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 
 # every symbol include/pmc.h and include/pmc_tuning.h declare
 SYMBOLS = ["pmc_abi_version", "pmc_last_error", "pmc_frame_layout_of", "pmc_create", "pmc_destroy", "pmc_bind_frames",
-           "pmc_clear_frames", "pmc_run_primary", "pmc_sync", "pmc_download", "pmc_frames_device", "pmc_frames_size",
+           "pmc_clear_frames", "pmc_run_primary", "pmc_set_progress", "pmc_sync", "pmc_download", "pmc_frames_device", "pmc_frames_size",
            "pmc_last_kernel_ms", "pmc_counters", "pmc_reset_counters", "pmc_trace_ray", "pmc_set_launch",
            "pmc_set_num_slots", "pmc_last_timing", "pmc_last_walk_timing", "pmc_walk_work", "pmc_radiation_field_size", "pmc_radiation_field_device",
            "pmc_download_radiation_field", "pmc_clear_radiation_field", "pmc_bind_radiation_field", "pmc_sampler_create",
@@ -222,6 +222,13 @@ class Engine:
     def run_primary(self, first, count, seed):
         """asynchronous launch of histories [first, first+count); accumulates into the frames"""
         _check(lib().pmc_run_primary(self._h, first, count, seed))
+
+    def set_progress(self, report, interval_seconds=3.0):
+        """report(launched, count) is called from run_primary at most once per interval (MonteCarloSimulation::logProgress); None: off"""
+        proto = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
+        self._progress = proto(lambda user, launched, count: report(int(launched), int(count))) if report else None  # (kept alive)
+        lib().pmc_set_progress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        _check(lib().pmc_set_progress(self._h, C.cast(self._progress, C.c_void_p) if self._progress else None, None, float(interval_seconds)))
 
     def sync(self):
         _check(lib().pmc_sync(self._h))

@@ -142,6 +142,12 @@ int main(int argc, char** argv)
         bool ok = pmc_create(skh_scene(sim), devices[g], &ctxs[g]) == PMC_OK;
         if (ok)
         {
+            // (the first device reports for all: MonteCarloSimulation::logProgress / Log::infoIfElapsed, every 3 s)
+            if (g == 0)
+                pmc_set_progress(ctxs[g], [](void*, uint64_t launched, uint64_t total) {
+                    printf("Launched primary emission photon packets: %.1f%%\n", total ? 100. * (double)launched / (double)total : 100.);
+                    fflush(stdout);
+                }, nullptr, 3.);
             uint64_t first = 0, count = 0;
             pmc_history_range(n, g, G, &first, &count);
             const int rc = pmc_run_primary(ctxs[g], first, count, (uint64_t)skh_seed(sim));

@@ -190,3 +190,27 @@ def test_one_wavelength_constants_equal_the_per_slot_arrays(monkeypatch):
         npix = lay.npix * lay.num_lambda
         assert np.array_equal(a[lay.wifu_offset:lay.wifu_offset + npix], b[lay.wifu_offset:lay.wifu_offset + npix]), name
         assert np.allclose(a, b, rtol=1e-11, atol=0), name
+
+
+@pytest.mark.gpu
+def test_progress_reports():
+    """MonteCarloSimulation::logProgress (MonteCarloSimulation.cpp:522-526, 609): pmc_set_progress reports the histories handed out so far
+    from the thread that runs pmc_run_primary, never more than the segment holds, never backwards"""
+    from skirt9_amd.engine import Engine
+    from skirt9_amd.host import Simulation
+    n = 300000
+    sim = Simulation(ski("cfg2small.ski"), num_packets=n).setup()
+    eng = Engine(sim.scene, 0)
+    seen = []
+    eng.set_progress(lambda launched, count: seen.append((launched, count)), interval_seconds=0.0)
+    eng.run_primary(0, n, 3)
+    eng.sync()
+    assert len(seen) >= 2
+    assert all(c == n for _, c in seen) and all(0 <= a <= n for a, _ in seen)
+    assert all(b[0] >= a[0] for a, b in zip(seen, seen[1:])) and seen[-1][0] == n
+    eng.set_progress(None)
+    count = len(seen)
+    eng.run_primary(n, 1000, 3)
+    eng.sync()
+    assert len(seen) == count and eng.counters()["histories"] == n + 1000
+    eng.close()
