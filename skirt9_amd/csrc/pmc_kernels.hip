@@ -80,7 +80,11 @@
     #define PMC_PROP_REFILL 40  // octree propagation kernel: likewise (its round includes the pass-1 -> pass-2 sampling)
 #endif
 #ifndef PMC_PEEL_BLOCK
-    #define PMC_PEEL_BLOCK 512  // lanes per workgroup of the peel-off kernel (one coordinate table in LDS per workgroup)
+    #define PMC_PEEL_BLOCK 768  // lanes per workgroup of the peel-off kernel (one coordinate table in LDS per workgroup): twelve waves, three per
+                                // SIMD (107 registers).  On the sorted records with the round-5 step 512 / 640 / 768 / 896 / 1024 lanes: 27.1 / 26.3 /
+                                // 24.5 / 25.1 / 25.9 ms per 2e7 packets in series; with the slot groups overlapped and 24 Mi slots 2.05 / 2.08 / 2.10e8
+                                // packets/s for 512 / 640 / 768 (profiles/sweeps/r05_c2_peel_block.txt, r05_d6_peel768_24m.txt; with 8 Mi slots the
+                                // larger workgroup gained nothing overlapped)
 #endif
 #ifndef PMC_PEEL_MIN_WAVES
     #define PMC_PEEL_MIN_WAVES 6  // waves per SIMD the peel-off kernel's register budget must allow (<= 80 VGPRs; it uses 75,
@@ -94,7 +98,8 @@
                                 // records come from LDS)
 #endif
 #ifndef PMC_PEEL_QCAP
-    #define PMC_PEEL_QCAP 128  // task records per wave queue of the peel-off kernel (a power of two >= 128: refilled 64 at a time)
+    #define PMC_PEEL_QCAP 64  // task records per wave queue of the peel-off kernel (a power of two >= 64: refilled 64 at a time, when it is empty;
+                              // 64 or 128 entries: the same times, and twelve queues of 64 fit next to the table of a 12-level octree)
 #endif
 #ifndef PMC_PROP_BLOCK
     #define PMC_PROP_BLOCK 768  // lanes per workgroup of the propagation kernel: ONE workgroup of twelve waves per CU -- three per SIMD, what
