@@ -143,6 +143,9 @@
 #endif
 static_assert(PMC_TRANSITION_BLOCK <= 256 && PMC_TRANSITION_BLOCK % 64 == 0,
               "the per-wave slot lists of the transition and launch kernels are laid out for at most four waves per workgroup");
+#ifndef PMC_SCAN_THREADS
+    #define PMC_SCAN_THREADS 256  // lanes of the one-workgroup scan kernels (endedScanKernel, rfScanKernel): see endedScanKernel
+#endif
 #ifndef PMC_TASK_CHUNK
     #define PMC_TASK_CHUNK 256  // slots a wave takes from the global cursor at a time (64 / 128 / 256 / 512 / 1024: 611 / 597 / 592 / 600 /
                                 // 623 ms per 1e8 packets, profiles/sweeps/r03_batch32_sweep.txt, r03_batch33_sweep.txt)
@@ -454,7 +457,7 @@ extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlo
     {
         unsigned long long* totals = static_cast<unsigned long long*>(temp[k]);
         hipLaunchKernelGGL(peelSortOffsetsKernel, dim3((PEEL_SORT_PARTS + 15) / 16), dim3(256), 0, stream, ps->matrix[k], (uint32_t)*groups, (uint32_t)PEEL_SORT_PARTS, totals);
-        hipLaunchKernelGGL(rfScanKernel, dim3(1), dim3(1024), 0, stream, totals, totals + PEEL_SORT_PARTS, (uint32_t)PEEL_SORT_PARTS);
+        hipLaunchKernelGGL(rfScanKernel, dim3(1), dim3(PMC_SCAN_THREADS), 0, stream, totals, totals + PEEL_SORT_PARTS, (uint32_t)PEEL_SORT_PARTS);
     }
     return hipGetLastError();
 }
@@ -527,7 +530,7 @@ static hipError_t launchPartition(const uint32_t* keys, const double* vals, uint
     const unsigned long long tiles = n / RF_TILE;
     const unsigned grid = (unsigned)std::min<unsigned long long>(tiles, (unsigned long long)numCU * 8ull);
     hipLaunchKernelGGL(rfHistKernel<BITS>, dim3(std::max(grid, 1u)), dim3(256), 0, stream, keys, n, (uint32_t)numParts, cursor, fills);
-    hipLaunchKernelGGL(rfScanKernel, dim3(1), dim3(1024), 0, stream, cursor, start, (uint32_t)numParts);
+    hipLaunchKernelGGL(rfScanKernel, dim3(1), dim3(PMC_SCAN_THREADS), 0, stream, cursor, start, (uint32_t)numParts);
     const size_t sortLds = size_t(RF_TILE) * (sizeof(double) + sizeof(uint32_t)) + size_t(2) * size_t(numParts) * sizeof(uint32_t);
     const unsigned sortGrid = (unsigned)std::min<unsigned long long>(tiles, (unsigned long long)numCU * 3ull);
     hipLaunchKernelGGL(rfScatterKernel<BITS>, dim3(std::max(sortGrid, 1u)), dim3(RF_SORT_BLOCK), sortLds, stream, keys, vals, n, (uint32_t)numParts, cursor, sortedKeys,
@@ -578,7 +581,7 @@ extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, 
     hipLaunchKernelGGL(transitionKernel, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group, seed, list, listLen, statLog ? *statLog : none);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || list) return e;  // (a sparse generation retires its ended histories in the transition kernel)
-    hipLaunchKernelGGL(endedScanKernel, dim3(1), dim3(1024), 0, stream, slot, slotBase, numSlots, group);
+    hipLaunchKernelGGL(endedScanKernel, dim3(1), dim3(PMC_SCAN_THREADS), 0, stream, slot, slotBase, numSlots, group);
     return hipGetLastError();
 }
 
