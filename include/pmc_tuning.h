@@ -14,7 +14,7 @@ extern "C" {
 /* A process-wide table of named switches, consulted by pmc_create / pmc_run_primary where the names below are listed in
    skirt9_amd/csrc/pmc_api.hip and pmc_kernels.hip (a switch is "set" when it has a value; numeric ones are parsed with atoi):
      PMC_SERIAL_WALKS, PMC_TIMING_DUMP, PMC_GEN_DUMP, PMC_PROFILE_DUMP        measurement: kernels of a group in series, dumps to stderr
-     PMC_NO_LIVE_LISTS, PMC_NO_PEEL_SORT, PMC_NO_XCD_AFFINITY, PMC_NO_MONO,
+     PMC_NO_LIVE_LISTS, PMC_NO_PEEL_SORT, PMC_NO_PROP_SORT, PMC_NO_XCD_AFFINITY, PMC_NO_MONO,
      PMC_RF_ATOMICS, PMC_RF_LOG_PER_SLOT, PMC_STAT_ATOMICS, PMC_STAT_LOG_ENTRIES, PMC_PEEL_V1, PMC_PROP_NO_CHECKPOINTS,
      PMC_VORO_NO_CULL, PMC_VORO_NO_OBSERVER_LISTS                              alternative code paths (cross-checks, A/B)
      PMC_WALK_BLOCKS_PER_CU, PMC_PEEL_BLOCKS_PER_CU, PMC_LAUNCH_BLOCKS_PER_CU,

@@ -1426,6 +1426,10 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             }
         if (observers <= PMC_SORT_OBS) numSortObs = observers;  // (more observers than that: all of them from the task arrays)
     }
+    // (Cartesian, Voronoi: one more list through the same sort -- the slots' PROPAGATION walks by the sign octant of their direction: with the
+    // XCD affinity of the walk stream the L2 of an XCD then sees the propagation walks of about one octant)
+    int propSortIndex = (!octree && numSortObs > 0 && numSortObs < PMC_SORT_OBS && pmcTune("PMC_NO_PROP_SORT") == nullptr) ? numSortObs : -1;
+    int numSortLists = numSortObs + (propSortIndex >= 0 ? 1 : 0);
     int listHalf[PMC_MAX_GROUPS] = {0, 0, 0, 0};  // the half of liveList that holds the group's current list
     int listTasksPerLane = 1;  // walks per lane that size the walk kernels' grids in a sparse generation
     if (const char* env = pmcTune("PMC_LIST_TASKS_PER_LANE")) listTasksPerLane = std::max(1, atoi(env));
@@ -1443,7 +1447,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     for (int g = 0; g < G && numSortObs > 0; ++g)
     {
         const int padded = (size[g] + 4095) / 4096 * 4096;
-        if (ctx->peelCap[g] >= padded && (octree ? (void*)ctx->peelRec[g][numSortObs - 1] : (void*)ctx->peelList[g][numSortObs - 1])) continue;
+        if (ctx->peelCap[g] >= padded && (octree ? (void*)ctx->peelRec[g][numSortObs - 1] : (void*)ctx->peelList[g][numSortLists - 1])) continue;
         HIP_TRY(hipDeviceSynchronize());
         // (a group that grows, or more observers than last time: the old buffers go first)
         for (int k = 0; k < PMC_SORT_OBS; ++k)
@@ -1459,13 +1463,13 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         // (no room for the records: the peel-off walks run from the task arrays, in slot order)
         size_t freeBytes = 0, totalBytes = 0;
         if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess
-            && size_t(numSortObs) * (size_t(padded) * sizeof(PeelRec) + pmcPeelSortTempBytes()) + (size_t(1) << 30) > freeBytes)
+            && size_t(numSortLists) * (size_t(padded) * sizeof(PeelRec) + pmcPeelSortTempBytes()) + (size_t(1) << 30) > freeBytes)
         {
-            numSortObs = 0;
+            numSortObs = 0, propSortIndex = -1, numSortLists = 0;
             break;
         }
         int rc;
-        for (int k = 0; k < numSortObs; ++k)
+        for (int k = 0; k < numSortLists; ++k)
         {
             if (octree && (rc = ctx->allocate<PeelRec>(padded, &ctx->peelRec[g][k], false, &ctx->rfAllocations))) return rc;
             if (!octree && (rc = ctx->allocate<int32_t>(padded, &ctx->peelList[g][k], false, &ctx->rfAllocations))) return rc;
@@ -1744,6 +1748,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                     for (int k = 0; k < numSortObs; ++k)
                         tasks.rec[k] = 1 + sortObs[k], tasks.list[k] = ctx->peelList[g][k], tasks.count[k] = pmcPeelSortedCount(ctx->peelTemp[g][k]);
                     tasks.xcdCursor = xcdAffinity ? ctx->xcdCursors + size_t(g) * PMC_SORT_OBS * 8 : nullptr;
+                    if (propSortIndex >= 0)
+                        tasks.propList = ctx->peelList[g][propSortIndex], tasks.propCount = pmcPeelSortedCount(ctx->peelTemp[g][propSortIndex]);
                 }
                 HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0) | (D.num_media > 1 ? 4 : 0), base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->block,
                                       ctx->walkLds, peelSorted[g] ? &tasks : nullptr, sg));
@@ -1773,6 +1779,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         PeelSortArgs sortArgs;
         std::memset(&sortArgs, 0, sizeof(sortArgs));
         sortArgs.numObs = numSortObs;
+        sortArgs.propIndex = propSortIndex;
         sortArgs.cap = (uint32_t)ctx->peelCap[g];
         for (int i = 0; i < 16; ++i) sortArgs.sortIndex[i] = -1;
         for (int k = 0; k < numSortObs; ++k) sortArgs.obs[k] = sortObs[k], sortArgs.sortIndex[sortObs[k]] = (int8_t)k;

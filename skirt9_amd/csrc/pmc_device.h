@@ -399,6 +399,8 @@ struct PeelRec
 struct PeelSortArgs  // sort-count kernel and cycle start kernel; numObs == 0: no sort, the walks' start states go to TaskArrays
 {
     int32_t numObs;                             // sorted observers
+    int32_t propIndex;                          // (Cartesian, Voronoi) index into the arrays below of the list of the PROPAGATION walks, sorted by the sign
+                                                // octant of their direction (partition = octant), or -1: the propagation walks run in slot order
     int32_t obs[PMC_SORT_OBS];                  // their instruments (the first of each observer group)
     int8_t sortIndex[16];                       // instrument -> index into the arrays below, or -1
     PeelRec* out[PMC_SORT_OBS];                 // (octree) the group's records in tile order, per observer
@@ -421,6 +423,8 @@ struct WalkStreamArgs
     const int32_t* list[PMC_SORT_OBS];
     const unsigned long long* count[PMC_SORT_OBS];  // entries of list k (device memory)
     unsigned long long* xcdCursor;                  // [8] (or null) one cursor per eighth of the stream: an XCD's workgroups take their own eighth first
+    const int32_t* propList;                        // (or null) the slots with a propagation walk, sorted by the sign octant of their direction: with the eighths
+    const unsigned long long* propCount;            // of the XCD affinity an XCD's L2 sees the walks of about one octant (its entries: device memory)
 };
 struct PeelSortedArgs  // peel-off kernel; rec == nullptr: task records from TaskArrays
 {

@@ -442,7 +442,8 @@ extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlo
                                               int* groups, hipStream_t stream)
 {
     ps->numParts = PEEL_SORT_PARTS;
-    for (int k = 0; k < ps->numObs; ++k)
+    const int numLists = ps->numObs + (ps->propIndex >= 0 ? 1 : 0);
+    for (int k = 0; k < numLists; ++k)
     {
         unsigned long long* totals = static_cast<unsigned long long*>(temp[k]);
         ps->out[k] = sorted ? sorted[k] : nullptr;
@@ -453,7 +454,7 @@ extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlo
     const int tiles = (numSlots + PEEL_SORT_TILE - 1) / PEEL_SORT_TILE;
     *groups = std::max(1, std::min(tiles, PEEL_SORT_GROUPS));
     hipLaunchKernelGGL(peelSortCountKernel, dim3(*groups), dim3(256), 0, stream, slot, slotBase, numSlots, *ps);
-    for (int k = 0; k < ps->numObs; ++k)
+    for (int k = 0; k < numLists; ++k)
     {
         unsigned long long* totals = static_cast<unsigned long long*>(temp[k]);
         hipLaunchKernelGGL(peelSortOffsetsKernel, dim3((PEEL_SORT_PARTS + 15) / 16), dim3(256), 0, stream, ps->matrix[k], (uint32_t)*groups, (uint32_t)PEEL_SORT_PARTS, totals);
@@ -606,7 +607,7 @@ extern "C" hipError_t pmcLaunchCycleStart(int slot, int gridKind, int slotBase, 
     {
         // (the sorts' cursors follow the grid tables in LDS; as many workgroups as the sort's count pass had: maxBlocks is that number then)
         ps.ldsOffset = int((ldsBytes + 15) & ~size_t(15));
-        ldsBytes = size_t(ps.ldsOffset) + size_t(ps.numObs) * PEEL_SORT_PARTS * sizeof(uint32_t);
+        ldsBytes = size_t(ps.ldsOffset) + size_t(ps.numObs + (ps.propIndex >= 0 ? 1 : 0)) * PEEL_SORT_PARTS * sizeof(uint32_t);
     }
     const int grid = std::max(1, std::min(((listIn ? listLen : numSlots) + 255) / 256, maxBlocks));
     if (gridKind == PMC_GRID_OCTREE)
