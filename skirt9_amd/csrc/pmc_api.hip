@@ -901,6 +901,19 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
                         D.vobs_of_inst[i] = (int8_t)k;
                         continue;
                     }
+                    // (memory: at most 32 B per neighbour entry + 64 B per cell and observer; the tables are an acceleration only, so an
+                    //  observer whose tables would take more than a quarter of the free device memory goes without, as do the later ones:
+                    //  their walks use the cone masks above)
+                    {
+                        size_t freeBytes = 0, totalBytes = 0;
+                        const size_t need = 32 * size_t(g.vnbr_start[ncell]) + 64 * size_t(ncell);
+                        if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && need > freeBytes / 4)
+                        {
+                            fprintf(stderr, "libpmc: per-observer Voronoi tables left out from observer %d on (%.1f GiB each, %.1f GiB free): peel-off walks use the cone masks\n",
+                                    k + 1, double(need) / double(1 << 30), double(freeBytes) / double(1 << 30));
+                            break;
+                        }
+                    }
                     ++k;
                     D.vobs_of_inst[i] = (int8_t)k;
                     // the cone of the observer's direction: as voroCone (pmc_walk.inc)
@@ -920,6 +933,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
                         const int subc = a >= b + c ? 0 : b >= a + c ? 1 : c >= a + b ? 2 : 3;
                         cone = cone * 4 + subc;
                     }
+                    const bool exactCull = !pmcTune("PMC_VORO_CONE_CULL_ONLY");
                     std::vector<double> opair, ohead(8 * size_t(ncell), 0.);
                     opair.reserve(4 * size_t(g.vnbr_start[ncell]) * 2 / 3);
                     for (int m = 0; m < ncell; ++m)
@@ -932,7 +946,18 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
                             if (j < 32 && ((mask >> j) & 1u)) continue;
                             const int mi = g.vnbr_list[q];
                             double e[4] = {0., 0., 0., 0.};
-                            if (mi >= 0) e[0] = g.site[3 * size_t(mi)], e[1] = g.site[3 * size_t(mi) + 1], e[2] = g.site[3 * size_t(mi) + 2];
+                            if (mi >= 0)
+                            {
+                                e[0] = g.site[3 * size_t(mi)], e[1] = g.site[3 * size_t(mi) + 1], e[2] = g.site[3 * size_t(mi) + 2];
+                                // ONE direction per observer: the candidate test of the walk itself (voroCandidate: n . k > 0, the same
+                                // doubles in the same order, no contraction) decides here which sites can ever be the exit -- half of them
+                                if (exactCull)
+                                {
+                                    const double nx = e[0] - g.site[3 * size_t(m)], ny = e[1] - g.site[3 * size_t(m) + 1], nz = e[2] - g.site[3 * size_t(m) + 2];
+                                    const double ndotk = nx * kx + ny * ky + nz * kz;
+                                    if (!(ndotk > 0)) continue;
+                                }
+                            }
                             const long long bits = mi;
                             std::memcpy(&e[3], &bits, sizeof(double));
                             opair.insert(opair.end(), e, e + 4);
