@@ -71,6 +71,9 @@ extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int tas
                                     int block, size_t ldsBytes, const WalkStreamArgs* tasks, hipStream_t stream);
 extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int sgn, int grid, size_t ldsBytes,
                                     const PeelRec* sortedRec, const unsigned long long* sortedCount, unsigned long long* xcdCursor, hipStream_t stream);
+extern "C" int pmcVoroPeelWavesPerSimd(void);
+extern "C" hipError_t pmcLaunchVoroPeel(int slot, int rec, int tab, const int32_t* list, const unsigned long long* count, unsigned long long* xcdCursor, int segments,
+                                        int grid, hipStream_t stream);
 extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, const int* list, int cursor, uint64_t seed, int grid,
                                     size_t ldsBytes, const RfLogArgs* rfLog, hipStream_t stream);
 extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n,
@@ -181,7 +184,7 @@ struct pmc_ctx
     PeelRec* peelRec[PMC_MAX_GROUPS][PMC_SORT_OBS]{};  // per group and sorted observer (octree)
     int32_t* peelList[PMC_MAX_GROUPS][PMC_SORT_OBS]{};  // (Cartesian, Voronoi) the slots in tile order instead
     void* peelTemp[PMC_MAX_GROUPS][PMC_SORT_OBS]{};
-    unsigned long long* xcdCursors{nullptr};  // [PMC_MAX_GROUPS][PMC_SORT_OBS][8] the peel-off kernels' cursors over the eighths of the sorted records
+    unsigned long long* xcdCursors{nullptr};  // [PMC_MAX_GROUPS][PMC_SORT_OBS + 1][8] (+ 8 that stay zero) the walk kernels' cursors over the eighths of their sorted records / lists
     int peelCap[PMC_MAX_GROUPS]{};
     size_t rfTempBytes{0};
     // statistics log per slot group (pmc_device.h StatLogArgs): the log and its partitioned copy, the sort's counters
@@ -934,12 +937,14 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
                         cone = cone * 4 + subc;
                     }
                     const bool exactCull = !pmcTune("PMC_VORO_CONE_CULL_ONLY");
-                    std::vector<double> opair, ohead(8 * size_t(ncell), 0.);
+                    // pass 1: the kept entries in list order, {site x, y, z, neighbour index} and where every cell's entries start
+                    std::vector<double> opair;
+                    std::vector<int32_t> first(size_t(ncell) + 1);
                     opair.reserve(4 * size_t(g.vnbr_start[ncell]) * 2 / 3);
                     for (int m = 0; m < ncell; ++m)
                     {
                         const uint32_t mask = cull[size_t(cone) * size_t(ncell) + size_t(m)];
-                        const int32_t first = int32_t(opair.size() / 4);
+                        first[m] = int32_t(opair.size() / 4);
                         for (int q = g.vnbr_start[m]; q < g.vnbr_start[m + 1]; ++q)
                         {
                             const int j = q - g.vnbr_start[m];
@@ -962,14 +967,52 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
                             std::memcpy(&e[3], &bits, sizeof(double));
                             opair.insert(opair.end(), e, e + 4);
                         }
-                        for (int a = 0; a < 3; ++a) ohead[8 * size_t(m) + a] = g.site[3 * size_t(m) + a];
-                        ohead[8 * size_t(m) + 3] = med.number_density[m];
-                        const int32_t bounds[2] = {first, int32_t(opair.size() / 4)};
-                        std::memcpy(&ohead[8 * size_t(m) + 4], bounds, sizeof(double));
                     }
-                    if (opair.empty()) opair.assign(4, 0.);
-                    if ((rc = ctx->upload(opair.data(), opair.size(), &D.vobs_pair[k]))) return bail(rc);
-                    if ((rc = ctx->upload(ohead.data(), ohead.size(), &D.vobs_head[k]))) return bail(rc);
+                    first[ncell] = int32_t(opair.size() / 4);
+                    // pass 2: ONE run of 64-byte units per cell -- header {site, density, number of entries}, then its entries in groups of
+                    // PMC_VORO_RUN_LANES, a group as {x, y} of each entry followed by {z, tag} of each: the lanes that share a walk read a
+                    // group with two coalesced loads.  An entry's tag carries the unit at which its neighbour's run starts next to the
+                    // neighbour's index (DevScene::vobs_run)
+                    constexpr size_t LANES = PMC_VORO_RUN_LANES, GROUP_UNITS = LANES / 2;
+                    std::vector<uint32_t> start(size_t(ncell) + 1);
+                    size_t units = 0;
+                    for (int m = 0; m < ncell; ++m)
+                    {
+                        start[m] = uint32_t(units);
+                        units += 1 + GROUP_UNITS * ((size_t(first[m + 1] - first[m]) + LANES - 1) / LANES);
+                    }
+                    if (units + PMC_VORO_RUN_PAD >= (size_t(1) << 32))
+                        return bail(fail(PMC_ERR_UNSUPPORTED, "Voronoi observer table beyond 2^32 units of 64 bytes"));
+                    std::vector<double> orun(8 * (units + PMC_VORO_RUN_PAD), 0.);  // (padding: a walk may request a group that the run does not have)
+                    const unsigned long long noEntry = (unsigned long long)(uint32_t)(-7);
+                    for (int m = 0; m < ncell; ++m)
+                    {
+                        double* head = &orun[8 * size_t(start[m])];
+                        for (int a = 0; a < 3; ++a) head[a] = g.site[3 * size_t(m) + a];
+                        head[3] = med.number_density[m];
+                        const int32_t count[2] = {first[m + 1] - first[m], 0};
+                        std::memcpy(&head[4], count, sizeof(double));
+                        const size_t groups = (size_t(count[0]) + LANES - 1) / LANES;
+                        for (size_t e = 0; e < groups * LANES; ++e)
+                        {
+                            double* group = head + 8 + 4 * LANES * (e / LANES);
+                            double* xy = group + 2 * (e % LANES);
+                            double* zt = group + 2 * LANES + 2 * (e % LANES);
+                            unsigned long long tag = noEntry;
+                            if (e < size_t(count[0]))
+                            {
+                                const double* src = &opair[4 * (size_t(first[m]) + e)];
+                                xy[0] = src[0], xy[1] = src[1], zt[0] = src[2];
+                                long long bits;
+                                std::memcpy(&bits, &src[3], sizeof(double));
+                                const int mi = int(bits);
+                                tag = (unsigned long long)(uint32_t)mi | (mi >= 0 ? (unsigned long long)start[mi] << 32 : 0ull);
+                            }
+                            std::memcpy(&zt[1], &tag, sizeof(double));
+                        }
+                    }
+                    if ((rc = ctx->upload(orun.data(), orun.size(), &D.vobs_run[k]))) return bail(rc);
+                    if ((rc = ctx->upload(start.data(), size_t(ncell), &D.vobs_start[k]))) return bail(rc);
                 }
             }
         }
@@ -1437,8 +1480,14 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     if (!ctx->xcdCursors)
     {
         int rc;
-        if ((rc = ctx->allocate<unsigned long long>(size_t(PMC_MAX_GROUPS) * PMC_SORT_OBS * 8, &ctx->xcdCursors, true, &ctx->rfAllocations))) return rc;
+        // (per group PMC_SORT_OBS + 1 sets of eight: set 0 the generic kernel's stream, 1 + k the Voronoi peel-off kernel of sorted observer k, and the
+        // octree's peel-off kernels sets 0 .. PMC_SORT_OBS - 1; one more set behind them all that is never written: a count of zero)
+        if ((rc = ctx->allocate<unsigned long long>((size_t(PMC_MAX_GROUPS) * (PMC_SORT_OBS + 1) + 1) * 8, &ctx->xcdCursors, true, &ctx->rfAllocations))) return rc;
     }
+    const auto cursorSet = [&](int g, int k) { return ctx->xcdCursors + (size_t(g) * (PMC_SORT_OBS + 1) + size_t(k)) * 8; };
+    const unsigned long long* const zeroCount = ctx->xcdCursors + size_t(PMC_MAX_GROUPS) * (PMC_SORT_OBS + 1) * 8;
+    // Voronoi, one medium component: the peel-off walks towards an observer that has a table of runs go through a kernel of their own
+    const bool voroPeelKernels = D.grid_kind == PMC_GRID_VORONOI && D.num_media <= 1 && pmcTune("PMC_VORO_NO_PEEL_KERNEL") == nullptr;
     const bool octree = D.grid_kind == PMC_GRID_OCTREE;
     if (pmcTune("PMC_NO_PEEL_SORT") == nullptr && (!octree || pmcPeelHasQueues((ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), ctx->walkLds)))
     {
@@ -1729,7 +1778,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 ctx->pinned[2 * PMC_MAX_GROUPS + g] = 0;
             }
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_TASK(g, 0), 0, PMC_CTR_TASKS_PER_GROUP * sizeof(unsigned long long), sg));  // task cursors
-            if (ctx->xcdCursors) HIP_TRY(hipMemsetAsync(ctx->xcdCursors + size_t(g) * PMC_SORT_OBS * 8, 0, PMC_SORT_OBS * 8 * sizeof(unsigned long long), sg));
+            if (ctx->xcdCursors) HIP_TRY(hipMemsetAsync(cursorSet(g, 0), 0, (PMC_SORT_OBS + 1) * 8 * sizeof(unsigned long long), sg));
             HIP_TRY(hipEventRecord(ctx->evA[g], sg));
             if (D.grid_kind == PMC_GRID_OCTREE)
             {
@@ -1752,7 +1801,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                         const bool sorted = peelSorted[g] && !list && k >= 0;
                         HIP_TRY(pmcLaunchPeel(ctx->slot, (ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), base[g], numTasks, sorted ? nullptr : list, PMC_CTR_TASK(g, 1 + i), i,
                                               (int)D.inst[i].sgn, peelGrid, ctx->walkLds, sorted ? ctx->peelRec[g][k] : nullptr, sorted ? pmcPeelSortedCount(ctx->peelTemp[g][k]) : nullptr,
-                                              sorted && xcdAffinity ? ctx->xcdCursors + (size_t(g) * PMC_SORT_OBS + k) * 8 : nullptr, sp));
+                                              sorted && xcdAffinity ? cursorSet(g, k) : nullptr, sp));
                     }
                 HIP_TRY(hipEventRecord(ctx->evJoin[g], sp));
                 RfLogArgs log = {ctx->rfKeys[g][0], ctx->rfVals[g][0], rfLogged ? ctx->rfCap[g] : 0ull, PMC_CTR_RFLOG(g), rfPadKey};
@@ -1772,12 +1821,20 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                     tasks.numLists = numSortObs;
                     for (int k = 0; k < numSortObs; ++k)
                         tasks.rec[k] = 1 + sortObs[k], tasks.list[k] = ctx->peelList[g][k], tasks.count[k] = pmcPeelSortedCount(ctx->peelTemp[g][k]);
-                    tasks.xcdCursor = xcdAffinity ? ctx->xcdCursors + size_t(g) * PMC_SORT_OBS * 8 : nullptr;
+                    tasks.xcdCursor = xcdAffinity ? cursorSet(g, 0) : nullptr;
                     if (propSortIndex >= 0)
                         tasks.propList = ctx->peelList[g][propSortIndex], tasks.propCount = pmcPeelSortedCount(ctx->peelTemp[g][propSortIndex]);
+                    // (lists that the Voronoi peel-off kernel takes, below: empty for the stream)
+                    for (int k = 0; k < numSortObs; ++k)
+                        if (voroPeelKernels && D.vobs_of_inst[sortObs[k]] >= 0) tasks.count[k] = zeroCount;
                 }
                 HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0) | (D.num_media > 1 ? 4 : 0), base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->block,
                                       ctx->walkLds, peelSorted[g] ? &tasks : nullptr, sg));
+                if (peelSorted[g])
+                    for (int k = 0; k < numSortObs; ++k)
+                        if (voroPeelKernels && D.vobs_of_inst[sortObs[k]] >= 0)
+                            HIP_TRY(pmcLaunchVoroPeel(ctx->slot, 1 + sortObs[k], D.vobs_of_inst[sortObs[k]], ctx->peelList[g][k], pmcPeelSortedCount(ctx->peelTemp[g][k]),
+                                                      cursorSet(g, 1 + k), xcdAffinity ? 8 : 1, ctx->numCU * pmcVoroPeelWavesPerSimd(), sg));
             }
             haveWalk[g] = true;
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));

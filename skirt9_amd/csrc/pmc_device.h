@@ -257,11 +257,14 @@ struct DevScene
                                   // words per neighbour from consecutive addresses instead of index -> site gathers
     const double* vhead;          // [num_cells][8]: per cell ONE 64-byte record {site x, y, z, number density, list start | list end
                                   // (two int32 in one double), 3 unused}: what a walk reads of the cell it enters, in one sector
-    // per observer (up to PMC_SORT_OBS; vobs_of_inst[instrument] = its table or -1): the neighbour entries a peel-off walk towards that observer
-    // has to look at -- the ones the mask of the observer's cone keeps, in list order, packed -- and the cells' header records with the bounds of
-    // those lists: such a walk reads no mask and 9 consecutive entries instead of 9 of 15 scattered ones (6.3 -> 3.8 lines per visit)
-    const double* vobs_head[4];
-    const double* vobs_pair[4];
+    // per observer (up to PMC_SORT_OBS; vobs_of_inst[instrument] = its table or -1): what a peel-off walk towards that observer reads of a cell, in ONE
+    // run of 64-byte units: a header {site x, y, z, number density, number of entries (int32)} and behind it the neighbour entries that can be the exit
+    // for the observer's direction (n . k_obs > 0, decided at setup by the walk's own test; domain walls as the cone's mask keeps them) in list order,
+    // 32 bytes each: {site x, y, z, tag = neighbour index (low 32 bits) | unit at which the neighbour's run starts (high 32 bits)}, stored in groups of
+    // PMC_VORO_RUN_LANES entries as {x, y} of every entry of the group, then {z, tag} of every entry (the last group filled up with tag -7): the
+    // PMC_VORO_RUN_LANES lanes that share a walk in voroPeelKernel read a group with two loads of adjacent 16-byte words
+    const double* vobs_run[4];
+    const uint32_t* vobs_start[4];  // [num_cells] first unit of the cell's run (a walk's first visit)
     int8_t vobs_of_inst[16];
     const uint32_t* vcull;        // [PMC_VORO_CONES][num_cells] (cone-major: a walk keeps its cone, and all peel-off walks towards an observer share
                                   // one: 4 bytes per cell of a 400 KB slice instead of one line per visit): per cell and direction cone (sign pattern of k x order of |k_x|, |k_y|,
@@ -436,6 +439,10 @@ struct PeelSortedArgs  // peel-off kernel; rec == nullptr: task records from Tas
 };
 #ifndef PMC_PEEL_TILES
 #define PMC_PEEL_TILES 32  // tiles per axis of the detector plane (PMC_PEEL_TILES^2 sort partitions)
+#endif
+#define PMC_VORO_RUN_PAD 16   // units of zeros behind the last run of DevScene::vobs_run
+#ifndef PMC_VORO_RUN_LANES
+#define PMC_VORO_RUN_LANES 2  // lanes that share a walk in voroPeelKernel = entries per group of a run (2 or 4)
 #endif
 #ifndef PMC_VORO_CONES
 #define PMC_VORO_CONES 192  // direction cones of DevScene::vcull: 48, or 192 (every cone divided at the midpoints of its edges)

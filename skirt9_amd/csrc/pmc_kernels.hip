@@ -131,6 +131,18 @@
 #ifndef PMC_VORO_UNROLL
     #define PMC_VORO_UNROLL 8  // Voronoi walk: neighbours whose gathers are in flight together (pmc_walk.inc voroEnter)
 #endif
+#ifndef PMC_VPEEL_MIN_WAVES
+    #define PMC_VPEEL_MIN_WAVES 4  // waves per SIMD the Voronoi peel-off kernel's register budget must allow
+#endif
+#ifndef PMC_VPEEL_ROWS
+    #define PMC_VPEEL_ROWS 4  // groups of PMC_VORO_RUN_LANES entries that the lanes of a walk request together (one round trip)
+#endif
+#ifndef PMC_VPEEL_REFILL
+    #define PMC_VPEEL_REFILL 16  // waiting lanes (PMC_VORO_RUN_LANES per walk) in a wave that trigger a service round of the Voronoi peel-off kernel
+#endif
+#ifndef PMC_VORO_RUN_FIRST
+    #define PMC_VORO_RUN_FIRST 4  // Voronoi peel-off walk: entries requested together with the header of a cell's run (voroEnterRun)
+#endif
 #ifndef PMC_VORO_CULL_ROUND
     #define PMC_VORO_CULL_ROUND 6  // Voronoi walk: neighbours per round of the masked exit search
 #endif
@@ -416,6 +428,16 @@ extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int tas
                                    walkKernel<GRID_VORO, false, true, true>,   walkKernel<GRID_VORO, true, true, true>};
     const Kernel kernel = gridKind == PMC_GRID_VORONOI ? voro[flavour] : cart[flavour];
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), ldsBytes, stream, slot, taskBase, numTaskRecords, taskCounter, seed, ws);
+    return hipGetLastError();
+}
+
+// Voronoi: the peel-off walks of the slots in `list` (their number: *count, device memory) towards the observer of task record `rec`, whose table of
+// runs is DevScene::vobs_run[tab]; xcdCursor: `segments` (8 or 1) zeroed cursors over equal parts of the list
+extern "C" int pmcVoroPeelWavesPerSimd(void) { return PMC_VPEEL_MIN_WAVES; }
+extern "C" hipError_t pmcLaunchVoroPeel(int slot, int rec, int tab, const int32_t* list, const unsigned long long* count, unsigned long long* xcdCursor, int segments,
+                                        int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(voroPeelKernel, dim3(grid), dim3(256), 0, stream, slot, rec, tab, list, count, xcdCursor, segments);
     return hipGetLastError();
 }
 
