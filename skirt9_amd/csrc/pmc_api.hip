@@ -1862,6 +1862,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         std::memset(&sortArgs, 0, sizeof(sortArgs));
         sortArgs.numObs = numSortObs;
         sortArgs.propIndex = propSortIndex;
+        for (int k = 0; k < PMC_SORT_OBS; ++k)
+            sortArgs.deferScan[k] = (sortNow && k < numSortObs && voroPeelKernels && D.vobs_of_inst[sortObs[k]] >= 0 && pmcTune("PMC_VORO_NO_DEFERRED_SCAN") == nullptr) ? 1 : 0;
         sortArgs.cap = (uint32_t)ctx->peelCap[g];
         for (int i = 0; i < 16; ++i) sortArgs.sortIndex[i] = -1;
         for (int k = 0; k < numSortObs; ++k) sortArgs.obs[k] = sortObs[k], sortArgs.sortIndex[sortObs[k]] = (int8_t)k;

@@ -412,6 +412,8 @@ struct PeelSortArgs  // sort-count kernel and cycle start kernel; numObs == 0: n
     const unsigned long long* start[PMC_SORT_OBS];  // [numParts + 1] first record of every partition (start[numParts] = number of records)
     uint32_t numParts;                          // PMC_PEEL_TILES^2
     uint32_t cap;                               // records (list entries) allocated per observer: a place beyond it is refused and counted (counters[7])
+    int8_t deferScan[PMC_SORT_OBS];             // (Voronoi) the walks of sorted observer k run in voroPeelKernel, which scans a walk's first cell itself: the cycle
+                                                // start kernel locates the cell and leaves the exit open (TaskArrays::cijk = PMC_VORO_FIRST_SCAN)
     int32_t ldsOffset;                          // cycle start kernel: where its cursors live in LDS (behind the grid tables): numObs x numParts
     double centre[3];                           // of the grid
     double scale;                               // PMC_PEEL_TILES / the grid's diagonal
@@ -440,6 +442,7 @@ struct PeelSortedArgs  // peel-off kernel; rec == nullptr: task records from Tas
 #ifndef PMC_PEEL_TILES
 #define PMC_PEEL_TILES 32  // tiles per axis of the detector plane (PMC_PEEL_TILES^2 sort partitions)
 #endif
+#define PMC_VORO_FIRST_SCAN (-1000)  // TaskArrays::cijk of a walk whose first cell has not been scanned for its exit yet
 #define PMC_VORO_RUN_PAD 16   // units of zeros behind the last run of DevScene::vobs_run
 #ifndef PMC_VORO_RUN_LANES
 #define PMC_VORO_RUN_LANES 2  // lanes that share a walk in voroPeelKernel = entries per group of a run (2 or 4)
