@@ -1099,6 +1099,8 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     int launchOnlyDoubles = 0;          // what only the launch kernel stages, behind the regions the two kernels share
 
     D.force_scattering = scene->options.force_scattering;
+    D.voro_defer_scan = (scene->grid.kind == PMC_GRID_VORONOI && scene->num_media <= 1 && pmcTune("PMC_VORO_NO_PEEL_KERNEL") == nullptr
+                         && pmcTune("PMC_VORO_NO_DEFERRED_SCAN") == nullptr) ? 1 : 0;
     D.min_weight_reduction = scene->options.min_weight_reduction;
     D.min_scatt_events = scene->options.min_scatt_events;
     D.path_length_bias = scene->options.path_length_bias;
@@ -1487,6 +1489,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     const auto cursorSet = [&](int g, int k) { return ctx->xcdCursors + (size_t(g) * (PMC_SORT_OBS + 1) + size_t(k)) * 8; };
     const unsigned long long* const zeroCount = ctx->xcdCursors + size_t(PMC_MAX_GROUPS) * (PMC_SORT_OBS + 1) * 8;
     // Voronoi, one medium component: the peel-off walks towards an observer that has a table of runs go through a kernel of their own
+    // (a switch set after pmc_create: the generic kernel knows a walk whose first cell is still to be scanned as well)
     const bool voroPeelKernels = D.grid_kind == PMC_GRID_VORONOI && D.num_media <= 1 && pmcTune("PMC_VORO_NO_PEEL_KERNEL") == nullptr;
     const bool octree = D.grid_kind == PMC_GRID_OCTREE;
     if (pmcTune("PMC_NO_PEEL_SORT") == nullptr && (!octree || pmcPeelHasQueues((ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), ctx->walkLds)))
@@ -1862,8 +1865,6 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         std::memset(&sortArgs, 0, sizeof(sortArgs));
         sortArgs.numObs = numSortObs;
         sortArgs.propIndex = propSortIndex;
-        for (int k = 0; k < PMC_SORT_OBS; ++k)
-            sortArgs.deferScan[k] = (sortNow && k < numSortObs && voroPeelKernels && D.vobs_of_inst[sortObs[k]] >= 0 && pmcTune("PMC_VORO_NO_DEFERRED_SCAN") == nullptr) ? 1 : 0;
         sortArgs.cap = (uint32_t)ctx->peelCap[g];
         for (int i = 0; i < 16; ++i) sortArgs.sortIndex[i] = -1;
         for (int k = 0; k < numSortObs; ++k) sortArgs.obs[k] = sortObs[k], sortArgs.sortIndex[sortObs[k]] = (int8_t)k;

@@ -288,6 +288,8 @@ struct DevScene
     double mono_lambda, mono_ext, mono_sca, mono_asym, mono_abs;
     // ---- options
     int32_t force_scattering;
+    int32_t voro_defer_scan;      // (Voronoi) the cycle start kernel locates the first cell of a walk and leaves its exit to the walk kernels, whose first step
+                                  // scans it like every other cell (TaskArrays::cijk = PMC_VORO_FIRST_SCAN)
     int32_t explicit_absorption;  // PhotonPacketOptions::explicitAbsorption (pmc.h pmc_options)
     // ---- several medium components (num_media > 1; else the members above describe the only one): MediumSystem.cpp:874-887, 678-730,
     // 796-817.  Component 0 is ALSO what the members above describe (the hot cell records carry its density).
@@ -412,8 +414,6 @@ struct PeelSortArgs  // sort-count kernel and cycle start kernel; numObs == 0: n
     const unsigned long long* start[PMC_SORT_OBS];  // [numParts + 1] first record of every partition (start[numParts] = number of records)
     uint32_t numParts;                          // PMC_PEEL_TILES^2
     uint32_t cap;                               // records (list entries) allocated per observer: a place beyond it is refused and counted (counters[7])
-    int8_t deferScan[PMC_SORT_OBS];             // (Voronoi) the walks of sorted observer k run in voroPeelKernel, which scans a walk's first cell itself: the cycle
-                                                // start kernel locates the cell and leaves the exit open (TaskArrays::cijk = PMC_VORO_FIRST_SCAN)
     int32_t ldsOffset;                          // cycle start kernel: where its cursors live in LDS (behind the grid tables): numObs x numParts
     double centre[3];                           // of the grid
     double scale;                               // PMC_PEEL_TILES / the grid's diagonal
