@@ -35,7 +35,9 @@ sys.path.insert(0, ROOT)
 
 SKI = os.path.join(ROOT, "tests", "ski", "cfg2.ski")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-VORONOI_KEPT_NEIGHBOURS = 0.60  # fraction of a Voronoi cell's neighbours the walk reads after the cone cull
+VORONOI_KEPT_NEIGHBOURS = 0.50  # fraction of a Voronoi cell's neighbours that can be the exit for ONE direction (n . k > 0): what a walk
+                                # has to read at least.  The peel-off walks read exactly those (observer tables, round 5), the propagation
+                                # walks the 60 % their cone's mask keeps: the smaller figure prices every visit
 # random dependent gathers per second of the whole chip with every lane on a trajectory of its own (profiles/microbench/
 # true_gather_mi355x.txt; the 2.1e11 of rounds 2-3 came from lanes that merged, profiles/r04_bridge.md): a 32 MB table without any
 # locality, and a table that fits the 4 MB L2 of an XCD -- the walk kernels' lane-step rates lie between the two by their locality
@@ -60,7 +62,7 @@ def pmc_traffic(packets_per_step):
     kib = allkib = 0.0
     for row in csv.DictReader(open(files[-1])):
         allkib += float(row["sum_KiB_per_step_of_2e7_packets"])
-        if row["kernel"] in ("walkKernel", "walkPeelKernel", "walkPropKernel"):
+        if row["kernel"] in ("walkKernel", "walkPeelKernel", "walkPropKernel", "voroPeelKernel"):
             kib += float(row["sum_KiB_per_step_of_2e7_packets"])
     scale = 1024.0 / 2e7 * packets_per_step
     return (kib * scale if kib else None), (allkib * scale if allkib else None), os.path.relpath(files[-1], ROOT)
@@ -424,9 +426,9 @@ def main():
             # Voronoi: a visit reads the cell's own record (site + density, 32 B) and, for each of its neighbours, the
             # neighbour index (4 B) and the neighbour's site (24 B) -- VoronoiMeshSnapshot.cpp:1096-1150; the mean
             # neighbour count is taken over the cells of the mesh (15.2 for tests/ski/cfg5.ski)
-            # the walk skips the neighbours that lie behind every direction of the walk's direction cone (DevScene::vcull, 192
-            # cones: 40 % of the neighbours of tests/ski/cfg5.ski): only the bytes of the neighbours it
-            # has to read count, so that `frac` cannot exceed what is read
+            # the walk skips the neighbours that cannot be the exit (n . k <= 0: half of them; the observer tables hold exactly the other
+            # half, the cone masks of the propagation walks keep 60 %): only the bytes of the neighbours every
+            # walk has to read count, so that `frac` cannot exceed what is read
             bytes_per_visit = 32.0 + 28.0 * m["vnbr_mean"] * VORONOI_KEPT_NEIGHBOURS
         n = max(1, m["packets_this_rank"])
         bytes_per_launch = bytes_per_visit * V + 8.0 * U
@@ -514,7 +516,7 @@ def main():
         roof["traffic_measured_in_run"] = False
         roof["traffic_source"] = (traffic_source + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/run_profile_set.sh) over a step of 2e7 packets, "
                                   "scaled by the packet count; `traffic` = the walk kernels, `traffic_all_kernels` = every kernel of the step") if traffic_source else None
-        roof["kernel"] = ("walkKernel<Voronoi>" if args.config == 5 else "walkPeelKernel + walkPropKernel (octree)") + \
+        roof["kernel"] = ("walkKernel<Voronoi> + voroPeelKernel" if args.config == 5 else "walkPeelKernel + walkPropKernel (octree)") + \
                          ": all launches of one step, overlapped on the slot groups' streams (denominator: segment_ms)"
         value = total_per_step * args.steps / main_run["elapsed"]
         out = {
