@@ -231,6 +231,13 @@ struct pmc_ctx
             e = hipMemset(d, 0, count * sizeof(T));
             if (e != hipSuccess) return hipFail(e, "hipMemset");
         }
+        else if (pmcTune("PMC_POISON_ALLOCATIONS"))
+        {
+            // (test aid: what the engine does not initialise holds neither zeros -- fresh device memory -- nor plausible values -- memory of a
+            // context destroyed before: a read of it shows)
+            e = hipMemset(d, 0xA5, count * sizeof(T));
+            if (e != hipSuccess) return hipFail(e, "hipMemset");
+        }
         *out = static_cast<T*>(d);
         return PMC_OK;
     }

@@ -284,6 +284,39 @@ def test_partition_independence():
     assert np.allclose(whole, split, rtol=1e-10, atol=1e-14 * np.abs(whole).max())
 
 
+@pytest.mark.parametrize("name", ["cfg2small.ski", "cfg1.ski", "cfg5small.ski", "cfg3small.ski", "cfg1rf.ski", "cfg2mm.ski", "cfg2ea.ski", "cfg1nf.ski"])
+def test_results_do_not_depend_on_what_device_memory_held(name):
+    """the engine zero-fills only the arrays whose zeros it relies on; everything else is written before it is read, also in the record
+    a walk kernel loads for a slot that turns out to have no walk.  With every other array filled with 0xA5 bytes at allocation
+    (PMC_POISON_ALLOCATIONS: neither the zeros of fresh device memory nor the plausible values a destroyed context leaves behind) the same
+    histories do the same work and fill the same frames -- and a second context created in the memory of a destroyed one runs like the first."""
+    from skirt9_amd.engine import Engine, set_tuning, clear_tuning
+    n = 20000
+    sim = Simulation(ski(name), num_packets=n).setup()
+
+    def run(engine):
+        engine.clear()
+        engine.reset_counters()
+        engine.run_primary(0, n, 4242)
+        c = engine.counters()
+        return engine.download(), (c["histories"], c["cell_visits"], c["scatterings"], c["detector_updates"])
+
+    keep = _engine(sim)
+    base, base_counts = run(keep)
+    set_tuning("PMC_POISON_ALLOCATIONS")
+    poisoned, counts = run(Engine(sim.scene, 0))
+    clear_tuning()
+    assert counts == base_counts
+    assert np.allclose(poisoned, base, rtol=1e-10, atol=1e-13 * np.abs(base).max())
+    # (slot reuse next to a live context: the second context's arrays land in what the first one's freed)
+    first = Engine(sim.scene, 0)
+    run(first)
+    del first
+    again, counts = run(Engine(sim.scene, 0))
+    assert counts == base_counts
+    assert np.allclose(again, base, rtol=1e-10, atol=1e-13 * np.abs(base).max())
+
+
 def test_fits_output_from_gpu(tmp_path):
     """end to end: ski -> scene -> GPU -> calibrated FITS/SED files with the reference's names"""
     n = 20000
