@@ -71,6 +71,9 @@ extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int tas
                                     int block, size_t ldsBytes, const WalkStreamArgs* tasks, hipStream_t stream);
 extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlots, const int* list, int cursor, int obs, int sgn, int grid, size_t ldsBytes,
                                     const PeelRec* sortedRec, const unsigned long long* sortedCount, unsigned long long* xcdCursor, hipStream_t stream);
+extern "C" int pmcVoroPropWavesPerSimd(void);
+extern "C" hipError_t pmcLaunchVoroProp(int slot, const int32_t* list, const unsigned long long* count, unsigned long long* xcdCursor, int segments, uint64_t seed,
+                                        int grid, hipStream_t stream);
 extern "C" int pmcVoroPeelWavesPerSimd(void);
 extern "C" hipError_t pmcLaunchVoroPeel(int slot, int rec, int tab, const int32_t* list, const unsigned long long* count, unsigned long long* xcdCursor, int segments,
                                         int grid, hipStream_t stream);
@@ -896,6 +899,113 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
                 for (auto& t : pool) t.join();
             }
             if ((rc = ctx->upload(cull.data(), cull.size(), &D.vcull))) return bail(rc);
+            // ---- a table of RUNS (DevScene::vobs_run, vgen_run): per cell ONE run of 64-byte units -- header {site, density, number of entries}, then its
+            // entries (first[m] .. first[m + 1] of `entries`: {site x, y, z, neighbour index}) in groups of PMC_VORO_RUN_LANES, a group as {x, y} of each
+            // entry followed by {z, tag} of each: the lanes that share a walk read a group with two coalesced loads.  An entry's tag carries the unit
+            // at which its neighbour's run starts next to the neighbour's index
+            const auto uploadRuns = [&](const std::vector<double>& entries, const std::vector<int32_t>& first, const double** runsOut, const uint32_t** startOut) -> int {
+                constexpr size_t LANES = PMC_VORO_RUN_LANES, GROUP_UNITS = LANES / 2;
+                std::vector<uint32_t> start(size_t(ncell) + 1);
+                size_t units = 0;
+                for (int m = 0; m < ncell; ++m)
+                {
+                    // (the link to the run: its first unit and, up to 30, the number of its entries -- pmc_device.h PMC_VORO_RUN_UNIT_BITS)
+                    const uint32_t entriesOf = uint32_t(first[m + 1] - first[m]);
+                    start[m] = uint32_t(units & PMC_VORO_RUN_UNIT_MASK) | (std::min(entriesOf, PMC_VORO_RUN_COUNT_UNKNOWN) << PMC_VORO_RUN_UNIT_BITS);
+                    units += 1 + GROUP_UNITS * ((size_t(entriesOf) + LANES - 1) / LANES);
+                }
+                if (units + PMC_VORO_RUN_PAD >= (size_t(1) << PMC_VORO_RUN_UNIT_BITS))
+                    return fail(PMC_ERR_UNSUPPORTED, "Voronoi table of runs beyond 2^27 units of 64 bytes");
+                std::vector<double> orun(8 * (units + PMC_VORO_RUN_PAD), 0.);  // (padding: a walk may request a group that the run does not have)
+                const unsigned long long noEntry = (unsigned long long)(uint32_t)(-7);
+                for (int m = 0; m < ncell; ++m)
+                {
+                    double* head = &orun[8 * size_t(start[m] & PMC_VORO_RUN_UNIT_MASK)];
+                    for (int a = 0; a < 3; ++a) head[a] = g.site[3 * size_t(m) + a];
+                    head[3] = med.number_density[m];
+                    const int32_t count[2] = {first[m + 1] - first[m], 0};
+                    std::memcpy(&head[4], count, sizeof(double));
+                    const size_t groups = (size_t(count[0]) + LANES - 1) / LANES;
+                    for (size_t e = 0; e < groups * LANES; ++e)
+                    {
+                        double* group = head + 8 + 4 * LANES * (e / LANES);
+                        double* xy = group + 2 * (e % LANES);
+                        double* zt = group + 2 * LANES + 2 * (e % LANES);
+                        unsigned long long tag = noEntry;
+                        if (e < size_t(count[0]))
+                        {
+                            const double* src = &entries[4 * (size_t(first[m]) + e)];
+                            xy[0] = src[0], xy[1] = src[1], zt[0] = src[2];
+                            long long bits;
+                            std::memcpy(&bits, &src[3], sizeof(double));
+                            const int mi = int(bits);
+                            tag = (unsigned long long)(uint32_t)mi | (mi >= 0 ? (unsigned long long)start[mi] << 32 : 0ull);
+                        }
+                        std::memcpy(&zt[1], &tag, sizeof(double));
+                    }
+                }
+                int rcu;
+                if ((rcu = ctx->upload(orun.data(), orun.size(), runsOut))) return rcu;
+                return ctx->upload(start.data(), size_t(ncell), startOut);
+            };
+            // ---- all neighbours of a cell as a run (DevScene::vgen_run): what a PROPAGATION walk in voroPropKernel reads -- no mask, one run of
+            // memory (4.75 lines per visit instead of header + mask + scattered entries: 6.2); left out where device memory is short
+            if (scene->num_media <= 1 && !pmcTune("PMC_VORO_NO_PROP_KERNEL"))
+            {
+                size_t freeBytes = 0, totalBytes = 0;
+                const size_t need = 32 * size_t(g.vnbr_start[ncell]) + 96 * size_t(ncell);
+                if (hipMemGetInfo(&freeBytes, &totalBytes) != hipSuccess || need <= freeBytes / 4)
+                {
+                    std::vector<double> all(4 * size_t(g.vnbr_start[ncell]), 0.);
+                    std::vector<int32_t> firstAll(size_t(ncell) + 1);
+                    for (int m = 0; m <= ncell; ++m) firstAll[m] = g.vnbr_start[m];
+                    for (int q = 0; q < g.vnbr_start[ncell]; ++q)
+                    {
+                        const int mi = g.vnbr_list[q];
+                        double* e = &all[4 * size_t(q)];
+                        if (mi >= 0) e[0] = g.site[3 * size_t(mi)], e[1] = g.site[3 * size_t(mi) + 1], e[2] = g.site[3 * size_t(mi) + 2];
+                        const long long bits = mi;
+                        std::memcpy(&e[3], &bits, sizeof(double));
+                    }
+                    if ((rc = uploadRuns(all, firstAll, &D.vgen_run, &D.vgen_start))) return bail(rc);
+                    // ... and per main cone the entries its sub-cones' masks keep (a neighbour beyond the 32nd is always kept)
+                    if (PMC_VORO_CONES == 192 && !pmcTune("PMC_VORO_NO_CONE_TABLES") && (hipMemGetInfo(&freeBytes, &totalBytes) != hipSuccess || 48 * need <= freeBytes / 4))
+                    {
+                        const int workers = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));
+                        for (int c0 = 0; c0 < 48; c0 += workers)
+                        {
+                            const int nc = std::min(workers, 48 - c0);
+                            std::vector<std::vector<double>> kept(nc);
+                            std::vector<std::vector<int32_t>> firstKept(nc);
+                            std::vector<std::thread> pool;
+                            for (int w = 0; w < nc; ++w)
+                                pool.emplace_back([&, w]() {
+                                    const int c = c0 + w;
+                                    std::vector<double>& e = kept[w];
+                                    std::vector<int32_t>& f = firstKept[w];
+                                    f.resize(size_t(ncell) + 1);
+                                    e.reserve(all.size() * 3 / 4);
+                                    for (int m = 0; m < ncell; ++m)
+                                    {
+                                        f[m] = int32_t(e.size() / 4);
+                                        uint32_t mask = 0xFFFFFFFFu;  // culled by every sub-cone
+                                        for (int sub = 0; sub < 4; ++sub) mask &= cull[size_t(4 * c + sub) * size_t(ncell) + size_t(m)];
+                                        for (int q = g.vnbr_start[m]; q < g.vnbr_start[m + 1]; ++q)
+                                        {
+                                            const int j = q - g.vnbr_start[m];
+                                            if (j < 32 && ((mask >> j) & 1u)) continue;
+                                            e.insert(e.end(), &all[4 * size_t(q)], &all[4 * size_t(q)] + 4);
+                                        }
+                                    }
+                                    f[ncell] = int32_t(e.size() / 4);
+                                });
+                            for (auto& t : pool) t.join();
+                            for (int w = 0; w < nc; ++w)
+                                if ((rc = uploadRuns(kept[w], firstKept[w], &D.vcone_run[c0 + w], &D.vcone_start[c0 + w]))) return bail(rc);
+                        }
+                    }
+                }
+            }
             // ---- per observer: the kept neighbour entries of its cone, packed (DevScene::vobs_*).  All peel-off walks towards an observer
             // have ONE direction, hence one cone and one mask per cell
             int observers = 0;
@@ -976,50 +1086,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
                         }
                     }
                     first[ncell] = int32_t(opair.size() / 4);
-                    // pass 2: ONE run of 64-byte units per cell -- header {site, density, number of entries}, then its entries in groups of
-                    // PMC_VORO_RUN_LANES, a group as {x, y} of each entry followed by {z, tag} of each: the lanes that share a walk read a
-                    // group with two coalesced loads.  An entry's tag carries the unit at which its neighbour's run starts next to the
-                    // neighbour's index (DevScene::vobs_run)
-                    constexpr size_t LANES = PMC_VORO_RUN_LANES, GROUP_UNITS = LANES / 2;
-                    std::vector<uint32_t> start(size_t(ncell) + 1);
-                    size_t units = 0;
-                    for (int m = 0; m < ncell; ++m)
-                    {
-                        start[m] = uint32_t(units);
-                        units += 1 + GROUP_UNITS * ((size_t(first[m + 1] - first[m]) + LANES - 1) / LANES);
-                    }
-                    if (units + PMC_VORO_RUN_PAD >= (size_t(1) << 32))
-                        return bail(fail(PMC_ERR_UNSUPPORTED, "Voronoi observer table beyond 2^32 units of 64 bytes"));
-                    std::vector<double> orun(8 * (units + PMC_VORO_RUN_PAD), 0.);  // (padding: a walk may request a group that the run does not have)
-                    const unsigned long long noEntry = (unsigned long long)(uint32_t)(-7);
-                    for (int m = 0; m < ncell; ++m)
-                    {
-                        double* head = &orun[8 * size_t(start[m])];
-                        for (int a = 0; a < 3; ++a) head[a] = g.site[3 * size_t(m) + a];
-                        head[3] = med.number_density[m];
-                        const int32_t count[2] = {first[m + 1] - first[m], 0};
-                        std::memcpy(&head[4], count, sizeof(double));
-                        const size_t groups = (size_t(count[0]) + LANES - 1) / LANES;
-                        for (size_t e = 0; e < groups * LANES; ++e)
-                        {
-                            double* group = head + 8 + 4 * LANES * (e / LANES);
-                            double* xy = group + 2 * (e % LANES);
-                            double* zt = group + 2 * LANES + 2 * (e % LANES);
-                            unsigned long long tag = noEntry;
-                            if (e < size_t(count[0]))
-                            {
-                                const double* src = &opair[4 * (size_t(first[m]) + e)];
-                                xy[0] = src[0], xy[1] = src[1], zt[0] = src[2];
-                                long long bits;
-                                std::memcpy(&bits, &src[3], sizeof(double));
-                                const int mi = int(bits);
-                                tag = (unsigned long long)(uint32_t)mi | (mi >= 0 ? (unsigned long long)start[mi] << 32 : 0ull);
-                            }
-                            std::memcpy(&zt[1], &tag, sizeof(double));
-                        }
-                    }
-                    if ((rc = ctx->upload(orun.data(), orun.size(), &D.vobs_run[k]))) return bail(rc);
-                    if ((rc = ctx->upload(start.data(), size_t(ncell), &D.vobs_start[k]))) return bail(rc);
+                    if ((rc = uploadRuns(opair, first, &D.vobs_run[k], &D.vobs_start[k]))) return bail(rc);
                 }
             }
         }
@@ -1106,8 +1173,12 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     int launchOnlyDoubles = 0;          // what only the launch kernel stages, behind the regions the two kernels share
 
     D.force_scattering = scene->options.force_scattering;
+    // (bit 0: peel-off walks of voroPeelKernel, bit 1: propagation walks of voroPropKernel)
     D.voro_defer_scan = (scene->grid.kind == PMC_GRID_VORONOI && scene->num_media <= 1 && pmcTune("PMC_VORO_NO_PEEL_KERNEL") == nullptr
                          && pmcTune("PMC_VORO_NO_DEFERRED_SCAN") == nullptr) ? 1 : 0;
+    if (scene->grid.kind == PMC_GRID_VORONOI && D.vgen_run && !scene->radiation_field.store && !scene->options.explicit_absorption
+        && pmcTune("PMC_VORO_NO_DEFERRED_SCAN") == nullptr)
+        D.voro_defer_scan |= 2;
     D.min_weight_reduction = scene->options.min_weight_reduction;
     D.min_scatt_events = scene->options.min_scatt_events;
     D.path_length_bias = scene->options.path_length_bias;
@@ -1498,6 +1569,9 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     // Voronoi, one medium component: the peel-off walks towards an observer that has a table of runs go through a kernel of their own
     // (a switch set after pmc_create: the generic kernel knows a walk whose first cell is still to be scanned as well)
     const bool voroPeelKernels = D.grid_kind == PMC_GRID_VORONOI && D.num_media <= 1 && pmcTune("PMC_VORO_NO_PEEL_KERNEL") == nullptr;
+    // ... and the propagation walks of the plain flavour, on the table of runs with all neighbours (when pmc_create built it)
+    const bool voroPropKernel = D.grid_kind == PMC_GRID_VORONOI && D.num_media <= 1 && D.vgen_run && !D.rf_store && !D.explicit_absorption
+                                && pmcTune("PMC_VORO_NO_PROP_KERNEL") == nullptr;
     const bool octree = D.grid_kind == PMC_GRID_OCTREE;
     if (pmcTune("PMC_NO_PEEL_SORT") == nullptr && (!octree || pmcPeelHasQueues((ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), ctx->walkLds)))
     {
@@ -1826,6 +1900,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 // order of the detector tile they start behind)
                 WalkStreamArgs tasks;
                 std::memset(&tasks, 0, sizeof(tasks));
+                bool streamEmpty = false;
                 if (peelSorted[g])
                 {
                     tasks.numLists = numSortObs;
@@ -1835,9 +1910,24 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                     if (propSortIndex >= 0)
                         tasks.propList = ctx->peelList[g][propSortIndex], tasks.propCount = pmcPeelSortedCount(ctx->peelTemp[g][propSortIndex]);
                     // (lists that the Voronoi peel-off kernel takes, below: empty for the stream)
+                    bool left = false;  // does the stream keep a list?
                     for (int k = 0; k < numSortObs; ++k)
-                        if (voroPeelKernels && D.vobs_of_inst[sortObs[k]] >= 0) tasks.count[k] = zeroCount;
+                        if (voroPeelKernels && D.vobs_of_inst[sortObs[k]] >= 0)
+                            tasks.count[k] = zeroCount;
+                        else
+                            left = true;
+                    const bool ownProp = voroPropKernel && propSortIndex >= 0;
+                    if (ownProp)
+                    {
+                        HIP_TRY(pmcLaunchVoroProp(ctx->slot, tasks.propList, tasks.propCount, cursorSet(g, PMC_SORT_OBS), xcdAffinity ? 8 : 1, seed,
+                                                  ctx->numCU * pmcVoroPropWavesPerSimd(), sg));
+                        tasks.propCount = zeroCount;
+                    }
+                    else
+                        left = true;
+                    streamEmpty = !left;
                 }
+                if (!streamEmpty)
                 HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0) | (D.num_media > 1 ? 4 : 0), base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->block,
                                       ctx->walkLds, peelSorted[g] ? &tasks : nullptr, sg));
                 if (peelSorted[g])

@@ -263,6 +263,13 @@ struct DevScene
     // 32 bytes each: {site x, y, z, tag = neighbour index (low 32 bits) | unit at which the neighbour's run starts (high 32 bits)}, stored in groups of
     // PMC_VORO_RUN_LANES entries as {x, y} of every entry of the group, then {z, tag} of every entry (the last group filled up with tag -7): the
     // PMC_VORO_RUN_LANES lanes that share a walk in voroPeelKernel read a group with two loads of adjacent 16-byte words
+    const double* vgen_run;         // (or null) ALL neighbours of a cell as a run of the same form: what a propagation walk in voroPropKernel reads
+    const uint32_t* vgen_start;     // [num_cells] first unit of the cell's run in vgen_run
+    // per main direction cone (48: sign octant x order of |k_x|, |k_y|, |k_z|; or null) the neighbours that the masks of its four sub-cones do not all
+    // cull, as a table of runs: a propagation walk keeps its cone, so voroPropKernel reads 65 % of the entries -- fewer lines of the 49 MB that
+    // miss L2 -- without a mask (1.7 GB at 10^5 sites: the tables are an acceleration, left out where device memory is short)
+    const double* vcone_run[48];
+    const uint32_t* vcone_start[48];
     const double* vobs_run[4];
     const uint32_t* vobs_start[4];  // [num_cells] first unit of the cell's run (a walk's first visit)
     int8_t vobs_of_inst[16];
@@ -442,6 +449,11 @@ struct PeelSortedArgs  // peel-off kernel; rec == nullptr: task records from Tas
 #ifndef PMC_PEEL_TILES
 #define PMC_PEEL_TILES 32  // tiles per axis of the detector plane (PMC_PEEL_TILES^2 sort partitions)
 #endif
+// a link to a run of a table of runs (an entry's tag, high 32 bits; DevScene::v*_start): first unit of the run | number of its entries << 27 (31: more than
+// 30, the header knows) -- a walk requests exactly the groups the next cell has, together with its header
+#define PMC_VORO_RUN_UNIT_BITS 27
+#define PMC_VORO_RUN_UNIT_MASK 0x07FFFFFFu
+#define PMC_VORO_RUN_COUNT_UNKNOWN 31u
 #define PMC_VORO_FIRST_SCAN (-1000)  // TaskArrays::cijk of a walk whose first cell has not been scanned for its exit yet
 #define PMC_VORO_RUN_PAD 16   // units of zeros behind the last run of DevScene::vobs_run
 #ifndef PMC_VORO_RUN_LANES

@@ -134,6 +134,15 @@
 #ifndef PMC_VPEEL_MIN_WAVES
     #define PMC_VPEEL_MIN_WAVES 4  // waves per SIMD the Voronoi peel-off kernel's register budget must allow
 #endif
+#ifndef PMC_VPROP_MIN_WAVES
+    #define PMC_VPROP_MIN_WAVES 3  // waves per SIMD the Voronoi propagation kernel's register budget must allow
+#endif
+#ifndef PMC_VPROP_ROWS
+    #define PMC_VPROP_ROWS 6  // groups of PMC_VORO_RUN_LANES entries that the lanes of a propagation walk request together (one round trip)
+#endif
+#ifndef PMC_VPROP_REFILL
+    #define PMC_VPROP_REFILL 16  // waiting lanes in a wave that trigger a service round of the Voronoi propagation kernel
+#endif
 #ifndef PMC_VPEEL_ROWS
     #define PMC_VPEEL_ROWS 4  // groups of PMC_VORO_RUN_LANES entries that the lanes of a walk request together (one round trip)
 #endif
@@ -438,6 +447,15 @@ extern "C" hipError_t pmcLaunchVoroPeel(int slot, int rec, int tab, const int32_
                                         int grid, hipStream_t stream)
 {
     hipLaunchKernelGGL(voroPeelKernel, dim3(grid), dim3(256), 0, stream, slot, rec, tab, list, count, xcdCursor, segments);
+    return hipGetLastError();
+}
+
+// Voronoi: the propagation walks (task record 0) of the slots in `list` on the table of runs DevScene::vgen_run
+extern "C" int pmcVoroPropWavesPerSimd(void) { return PMC_VPROP_MIN_WAVES; }
+extern "C" hipError_t pmcLaunchVoroProp(int slot, const int32_t* list, const unsigned long long* count, unsigned long long* xcdCursor, int segments, uint64_t seed,
+                                        int grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(voroPropKernel, dim3(grid), dim3(256), 0, stream, slot, list, count, xcdCursor, segments, seed);
     return hipGetLastError();
 }
 

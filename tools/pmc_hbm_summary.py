@@ -15,7 +15,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     calls = collections.defaultdict(set)
     for f in glob.glob(f"{run}/pmc_{counter}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            m = re.search(r"(voroPeelKernel|walkPeelKernel|walkPropKernel|walkKernel|transitionKernel|launchKernel|cycleStartKernel|endedScanKernel|statMergeKernel|peelSortCountKernel|peelSortOffsetsKernel|peelSortScatterKernel|rfHistKernel|rfScanKernel|rfScatterKernel|rfReduceKernel)", row["Kernel_Name"])
+            m = re.search(r"(voroPropKernel|voroPeelKernel|walkPeelKernel|walkPropKernel|walkKernel|transitionKernel|launchKernel|cycleStartKernel|endedScanKernel|statMergeKernel|peelSortCountKernel|peelSortOffsetsKernel|peelSortScatterKernel|rfHistKernel|rfScanKernel|rfScatterKernel|rfReduceKernel)", row["Kernel_Name"])
             if not m or row["Counter_Name"] != counter:
                 continue
             tot[m.group(1)] += float(row["Counter_Value"])

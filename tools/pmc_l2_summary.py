@@ -15,7 +15,7 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(set)
 for f in glob.glob(f"{run}/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        m = re.search(r"(voroPeelKernel|walkPeelKernel|walkPropKernel|walkKernel|transitionKernel|launchKernel|cycleStartKernel|endedScanKernel|statMergeKernel|peelSortCountKernel|peelSortOffsetsKernel|rfHistKernel|rfScanKernel|rfScatterKernel|rfReduceKernel|statReduceKernel)", row["Kernel_Name"])
+        m = re.search(r"(voroPropKernel|voroPeelKernel|walkPeelKernel|walkPropKernel|walkKernel|transitionKernel|launchKernel|cycleStartKernel|endedScanKernel|statMergeKernel|peelSortCountKernel|peelSortOffsetsKernel|rfHistKernel|rfScanKernel|rfScatterKernel|rfReduceKernel|statReduceKernel)", row["Kernel_Name"])
         if not m or row["Counter_Name"] not in names:
             continue
         tot[m.group(1)][row["Counter_Name"]] += float(row["Counter_Value"])

@@ -13,7 +13,7 @@ import csv, glob, collections, re, sys
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(sys.argv[1] + "/pass/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        m = re.search(r"(voroPeelKernel|walkPeelKernel|walkPropKernel|walkKernel|transitionKernel|launchKernel|cycleStartKernel|endedScanKernel|statMergeKernel)", row["Kernel_Name"])
+        m = re.search(r"(voroPropKernel|voroPeelKernel|walkPeelKernel|walkPropKernel|walkKernel|transitionKernel|launchKernel|cycleStartKernel|endedScanKernel|statMergeKernel)", row["Kernel_Name"])
         if m: tot[m.group(1)][row["Counter_Name"]] += float(row["Counter_Value"])
 for k in sorted(tot):
     print(f"{k:18s} " + "  ".join(f"{c} {v:.4e}" for c, v in sorted(tot[k].items())))
