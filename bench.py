@@ -62,7 +62,7 @@ def pmc_traffic(packets_per_step):
     kib = allkib = 0.0
     for row in csv.DictReader(open(files[-1])):
         allkib += float(row["sum_KiB_per_step_of_2e7_packets"])
-        if row["kernel"] in ("walkKernel", "walkPeelKernel", "walkPropKernel", "voroPeelKernel"):
+        if row["kernel"] in ("walkKernel", "walkPeelKernel", "walkPropKernel", "voroPeelKernel", "voroPropKernel"):
             kib += float(row["sum_KiB_per_step_of_2e7_packets"])
     scale = 1024.0 / 2e7 * packets_per_step
     return (kib * scale if kib else None), (allkib * scale if allkib else None), os.path.relpath(files[-1], ROOT)
@@ -516,7 +516,7 @@ def main():
         roof["traffic_measured_in_run"] = False
         roof["traffic_source"] = (traffic_source + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/run_profile_set.sh) over a step of 2e7 packets, "
                                   "scaled by the packet count; `traffic` = the walk kernels, `traffic_all_kernels` = every kernel of the step") if traffic_source else None
-        roof["kernel"] = ("walkKernel<Voronoi> + voroPeelKernel" if args.config == 5 else "walkPeelKernel + walkPropKernel (octree)") + \
+        roof["kernel"] = ("voroPropKernel + voroPeelKernel (Voronoi)" if args.config == 5 else "walkPeelKernel + walkPropKernel (octree)") + \
                          ": all launches of one step, overlapped on the slot groups' streams (denominator: segment_ms)"
         value = total_per_step * args.steps / main_run["elapsed"]
         out = {
