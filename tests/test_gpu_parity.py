@@ -190,6 +190,37 @@ def test_explicit_absorption_matches_oracle(name, n, tmp_path):
     _compare_frames(sim, gpu, ref, n)
 
 
+@pytest.mark.parametrize("changes", [{'forceScattering="true"': 'forceScattering="false"'},
+                                     {'pathLengthBias="0.5"': 'pathLengthBias="0"'},
+                                     {'pathLengthBias="0.5"': 'pathLengthBias="1"', 'minWeightReduction="1e4"': 'minWeightReduction="1e2"'}])
+def test_voronoi_propagation_kernel_options(changes, tmp_path):
+    """voroPropKernel (the propagation walks of a Voronoi grid, two lanes per walk) in the cycles the plain scene does not reach: without forced
+    scattering (one walk up to the drawn depth, escapes), and with the path-length bias at its ends (exponential deviates only -- the branch with
+    a rejection round that continues the slot's random stream --, uniform deviates only) -- HIP engine against the oracle on the reduced
+    configs[4] scene"""
+    import shutil
+    name, n = "cfg5small.ski", 30000
+    text = open(ski(name)).read()
+    for old, new in changes.items():
+        assert old in text
+        text = text.replace(old, new)
+    for f in os.listdir(os.path.dirname(ski(name))):
+        if f.endswith(".txt"):
+            shutil.copy(ski(f), tmp_path / f)
+    path = tmp_path / "cfg5variant.ski"
+    path.write_text(text)
+    sim = Simulation(str(path), num_packets=n).setup()
+    eng = _engine(sim)
+    eng.run_primary(0, n, 31337)
+    gpu = eng.download()
+    ref, counters = O.run_primary(sim, 0, n, O.RNG_PHILOX, seed=31337)
+    c = eng.counters()
+    assert c["histories"] == n and c["stat_overflows"] == 0
+    assert abs(c["cell_visits"] - counters.cell_visits) <= 1e-4 * counters.cell_visits
+    assert abs(c["scatterings"] - counters.scatterings) <= 1e-4 * counters.scatterings + 2
+    _compare_frames(sim, gpu, ref, n)
+
+
 SECOND_COMPONENT = """</GeometricMedium><GeometricMedium velocityMagnitude="0 km/s" magneticFieldStrength="0 uG">
      <geometry type="Geometry"><PlummerGeometry scaleLength="1500 pc"/></geometry>
      <materialMix type="MaterialMix"><MeanListDustMix wavelengths="0.1 micron, 1 micron" extinctionCoefficients="5000 m2/kg, 1200 m2/kg" albedos="0.8, 0.4" asymmetryParameters="0.1, 0.9"/></materialMix>
