@@ -147,7 +147,7 @@
     #define PMC_VPEEL_ROWS 4  // groups of PMC_VORO_RUN_LANES entries that the lanes of a walk request together (one round trip)
 #endif
 #ifndef PMC_VPEEL_REFILL
-    #define PMC_VPEEL_REFILL 16  // waiting lanes (PMC_VORO_RUN_LANES per walk) in a wave that trigger a service round of the Voronoi peel-off kernel
+    #define PMC_VPEEL_REFILL 8  // waiting lanes (PMC_VORO_RUN_LANES per walk) in a wave that trigger a service round of the Voronoi peel-off kernel (2 / 4 / 8 / 16 / 32 on configs[4]: 551 / 549 / 549 / 558 / 593 ms of walk kernels per 2e7 packets)
 #endif
 #ifndef PMC_VORO_RUN_FIRST
     #define PMC_VORO_RUN_FIRST 4  // Voronoi peel-off walk: entries requested together with the header of a cell's run (voroEnterRun)
