@@ -1173,6 +1173,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     int launchOnlyDoubles = 0;          // what only the launch kernel stages, behind the regions the two kernels share
 
     D.force_scattering = scene->options.force_scattering;
+    D.voro_prop_checkpoints = pmcTune("PMC_PROP_NO_CHECKPOINTS") == nullptr ? 1 : 0;
     // (bit 0: peel-off walks of voroPeelKernel, bit 1: propagation walks of voroPropKernel)
     D.voro_defer_scan = (scene->grid.kind == PMC_GRID_VORONOI && scene->num_media <= 1 && pmcTune("PMC_VORO_NO_PEEL_KERNEL") == nullptr
                          && pmcTune("PMC_VORO_NO_DEFERRED_SCAN") == nullptr) ? 1 : 0;

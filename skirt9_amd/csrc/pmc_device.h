@@ -295,6 +295,7 @@ struct DevScene
     double mono_lambda, mono_ext, mono_sca, mono_asym, mono_abs;
     // ---- options
     int32_t force_scattering;
+    int32_t voro_prop_checkpoints;  // (Voronoi) voroPropKernel keeps two pass-1 walker states per walk in LDS for pass 2 (off: tuning switch PMC_PROP_NO_CHECKPOINTS)
     int32_t voro_defer_scan;      // (Voronoi) the cycle start kernel locates the first cell of a walk and leaves its exit to the walk kernels, whose first step
                                   // scans it like every other cell (TaskArrays::cijk = PMC_VORO_FIRST_SCAN)
     int32_t explicit_absorption;  // PhotonPacketOptions::explicitAbsorption (pmc.h pmc_options)
