@@ -137,6 +137,9 @@
 #ifndef PMC_VPROP_MIN_WAVES
     #define PMC_VPROP_MIN_WAVES 3  // waves per SIMD the Voronoi propagation kernel's register budget must allow
 #endif
+#ifndef PMC_VPROP_STEPS
+    #define PMC_VPROP_STEPS 4  // scan steps of the Voronoi propagation kernel between two round checks = the tick of its checkpoints (3 / 4 / 6 / 8 / 12 on configs[4]: 514.7 / 514.9 / 516.7 / 518 / 524 ms of walk kernels per 2e7 packets)
+#endif
 #ifndef PMC_VPROP_ROWS
     #define PMC_VPROP_ROWS 6  // groups of PMC_VORO_RUN_LANES entries that the lanes of a propagation walk request together (one round trip)
 #endif
