@@ -905,13 +905,16 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
             // at which its neighbour's run starts next to the neighbour's index
             const auto uploadRuns = [&](const std::vector<double>& entries, const std::vector<int32_t>& first, const double** runsOut, const uint32_t** startOut) -> int {
                 constexpr size_t LANES = PMC_VORO_RUN_LANES, GROUP_UNITS = LANES / 2;
+                // (cells with more entries than a link can name -- 30 -- say so in their header; PMC_VORO_LINK_COUNT_MAX lowers the limit: a test of that path)
+                uint32_t linkCountMax = PMC_VORO_RUN_COUNT_UNKNOWN - 1u;
+                if (const char* v = pmcTune("PMC_VORO_LINK_COUNT_MAX")) linkCountMax = std::min<uint32_t>(linkCountMax, (uint32_t)std::max(0, atoi(v)));
                 std::vector<uint32_t> start(size_t(ncell) + 1);
                 size_t units = 0;
                 for (int m = 0; m < ncell; ++m)
                 {
                     // (the link to the run: its first unit and, up to 30, the number of its entries -- pmc_device.h PMC_VORO_RUN_UNIT_BITS)
                     const uint32_t entriesOf = uint32_t(first[m + 1] - first[m]);
-                    start[m] = uint32_t(units & PMC_VORO_RUN_UNIT_MASK) | (std::min(entriesOf, PMC_VORO_RUN_COUNT_UNKNOWN) << PMC_VORO_RUN_UNIT_BITS);
+                    start[m] = uint32_t(units & PMC_VORO_RUN_UNIT_MASK) | ((entriesOf > linkCountMax ? PMC_VORO_RUN_COUNT_UNKNOWN : entriesOf) << PMC_VORO_RUN_UNIT_BITS);
                     units += 1 + GROUP_UNITS * ((size_t(entriesOf) + LANES - 1) / LANES);
                 }
                 if (units + PMC_VORO_RUN_PAD >= (size_t(1) << PMC_VORO_RUN_UNIT_BITS))
