@@ -1920,10 +1920,12 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                             tasks.count[k] = zeroCount;
                         else
                             left = true;
+                    // (the list is in cone order: ONE cursor, all XCDs on the same cone table at a time -- 490 against 493 ms of walk kernels per 2e7 packets
+                    // with an eighth of the list per XCD, profiles/sweeps/r05_i15)
                     const bool ownProp = voroPropKernel && propSortIndex >= 0;
                     if (ownProp)
                     {
-                        HIP_TRY(pmcLaunchVoroProp(ctx->slot, tasks.propList, tasks.propCount, cursorSet(g, PMC_SORT_OBS), xcdAffinity ? 8 : 1, seed,
+                        HIP_TRY(pmcLaunchVoroProp(ctx->slot, tasks.propList, tasks.propCount, cursorSet(g, PMC_SORT_OBS), (xcdAffinity && pmcTune("PMC_VPROP_XCD_SEGMENTS")) ? 8 : 1, seed,
                                                   ctx->numCU * pmcVoroPropWavesPerSimd(), sg));
                         tasks.propCount = zeroCount;
                     }
