@@ -16,7 +16,7 @@ extern "C" {
      PMC_SERIAL_WALKS, PMC_TIMING_DUMP, PMC_GEN_DUMP, PMC_PROFILE_DUMP        measurement: kernels of a group in series, dumps to stderr
      PMC_NO_LIVE_LISTS, PMC_NO_PEEL_SORT, PMC_NO_PROP_SORT, PMC_NO_XCD_AFFINITY, PMC_NO_MONO,
      PMC_RF_ATOMICS, PMC_RF_LOG_PER_SLOT, PMC_STAT_ATOMICS, PMC_STAT_LOG_ENTRIES, PMC_PEEL_V1, PMC_PROP_NO_CHECKPOINTS (octree: at run; Voronoi: at pmc_create),
-     PMC_VORO_NO_CULL, PMC_VORO_NO_OBSERVER_LISTS, PMC_VORO_CONE_CULL_ONLY, PMC_VORO_NO_PEEL_KERNEL, PMC_VORO_NO_PROP_KERNEL, PMC_VORO_NO_CONE_TABLES, PMC_VORO_NO_DEFERRED_SCAN, PMC_VORO_LINK_COUNT_MAX, PMC_VPROP_XCD_SEGMENTS,
+     PMC_VORO_NO_CULL, PMC_VORO_NO_OBSERVER_LISTS, PMC_VORO_CONE_CULL_ONLY, PMC_VORO_NO_PEEL_KERNEL, PMC_VORO_NO_PROP_KERNEL, PMC_VORO_NO_CONE_TABLES, PMC_VORO_NO_DEFERRED_SCAN, PMC_VORO_LINK_COUNT_MAX, PMC_VPROP_XCD_SEGMENTS, PMC_VORO_WALKS_IN_SERIES, PMC_VPROP_BLOCKS_PER_CU, PMC_VPEEL_BLOCKS_PER_CU,
      PMC_POISON_ALLOCATIONS (test aid: device arrays the engine does not initialise are filled with 0xA5 bytes)                          alternative code paths (cross-checks, A/B)
      PMC_WALK_BLOCKS_PER_CU, PMC_PEEL_BLOCKS_PER_CU, PMC_LAUNCH_BLOCKS_PER_CU,
      PMC_CYCLE_BLOCKS_PER_CU, PMC_TRANSITION_BLOCKS_PER_CU,

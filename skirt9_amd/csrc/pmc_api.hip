@@ -1925,8 +1925,10 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                     const bool ownProp = voroPropKernel && propSortIndex >= 0;
                     if (ownProp)
                     {
+                        int propBlocks = pmcVoroPropWavesPerSimd();
+                        if (const char* v = pmcTune("PMC_VPROP_BLOCKS_PER_CU")) propBlocks = std::max(1, atoi(v));
                         HIP_TRY(pmcLaunchVoroProp(ctx->slot, tasks.propList, tasks.propCount, cursorSet(g, PMC_SORT_OBS), (xcdAffinity && pmcTune("PMC_VPROP_XCD_SEGMENTS")) ? 8 : 1, seed,
-                                                  ctx->numCU * pmcVoroPropWavesPerSimd(), sg));
+                                                  ctx->numCU * propBlocks, sg));
                         tasks.propCount = zeroCount;
                     }
                     else
@@ -1937,10 +1939,26 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 HIP_TRY(pmcLaunchWalk(ctx->slot, D.grid_kind, (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0) | (D.num_media > 1 ? 4 : 0), base[g], size[g], PMC_CTR_TASK(g, 0), seed, ctx->grid, ctx->block,
                                       ctx->walkLds, peelSorted[g] ? &tasks : nullptr, sg));
                 if (peelSorted[g])
+                {
+                    // the peel-off kernels on the group's side stream next to the propagation kernel (as on the octree: one is bound by the lines it
+                    // gets from beyond L2, the others by instructions and the L1's access rate); `PMC_VORO_WALKS_IN_SERIES`: behind it, one stream
+                    bool anyPeel = false;
+                    for (int k = 0; k < numSortObs; ++k) anyPeel = anyPeel || (voroPeelKernels && D.vobs_of_inst[sortObs[k]] >= 0);
+                    const bool side = anyPeel && voroPropKernel && propSortIndex >= 0 && !serialWalks && pmcTune("PMC_VORO_WALKS_IN_SERIES") == nullptr;
+                    hipStream_t sp = side ? ctx->peelStream[g] : sg;
+                    int peelBlocks = pmcVoroPeelWavesPerSimd();
+                    if (const char* v = pmcTune("PMC_VPEEL_BLOCKS_PER_CU")) peelBlocks = std::max(1, atoi(v));
+                    if (side) HIP_TRY(hipStreamWaitEvent(sp, ctx->evA[g], 0));
                     for (int k = 0; k < numSortObs; ++k)
                         if (voroPeelKernels && D.vobs_of_inst[sortObs[k]] >= 0)
                             HIP_TRY(pmcLaunchVoroPeel(ctx->slot, 1 + sortObs[k], D.vobs_of_inst[sortObs[k]], ctx->peelList[g][k], pmcPeelSortedCount(ctx->peelTemp[g][k]),
-                                                      cursorSet(g, 1 + k), xcdAffinity ? 8 : 1, ctx->numCU * pmcVoroPeelWavesPerSimd(), sg));
+                                                      cursorSet(g, 1 + k), xcdAffinity ? 8 : 1, ctx->numCU * peelBlocks, sp));
+                    if (side)
+                    {
+                        HIP_TRY(hipEventRecord(ctx->evJoin[g], sp));
+                        HIP_TRY(hipStreamWaitEvent(sg, ctx->evJoin[g], 0));
+                    }
+                }
             }
             haveWalk[g] = true;
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
