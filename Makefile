@@ -5,7 +5,9 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 # host code generation matches the reference's Release build (-O3, no -march => no FMA contraction) so that
 # setup-time tables are bit-identical to SKIRT's
 CXXFLAGS := -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter
-HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Wall -Wno-unused-parameter -Wno-unused-value
+HIPFLAGS_CODE := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics
+# (the flags that decide the generated code are recorded in the binary: pmc_build_info)
+HIPFLAGS := $(HIPFLAGS_CODE) -Wall -Wno-unused-parameter -Wno-unused-value -DPMC_BUILD_FLAGS='"$(HIPFLAGS_CODE)"'
 
 HOST_SRC := $(wildcard skirt9_amd/host/*.cpp)
 HOST_HDR := $(wildcard skirt9_amd/host/*.hpp) $(wildcard include/*.h)

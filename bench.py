@@ -159,11 +159,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # launched plainly (`python bench.py --gpus N`): start the N ranks here -- one process per GPU under torch.distributed.run, the
+            # form the driver uses -- and hand their output through; the JSON line of rank 0 stays the last line on stdout
+            if torch.cuda.device_count() < args.gpus and os.environ.get("BENCH_SHARE_DEVICE") != "1":
+                raise SystemExit(f"--gpus {args.gpus}: this box has {torch.cuda.device_count()} device(s) (BENCH_SHARE_DEVICE=1 runs all ranks "
+                                 "on device 0 with the exchange over gloo: a flow check, not a measurement)")
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            raise SystemExit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                              "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
     # testing aid for a 1-GPU box: BENCH_SHARE_DEVICE=1 runs all ranks on device 0 and exchanges over gloo (RCCL refuses
     # two ranks on one device); the history split, the per-step reduce and the timing protocol are the same
     share = world > 1 and os.environ.get("BENCH_SHARE_DEVICE") == "1"

@@ -285,6 +285,10 @@ typedef struct pmc_ctx pmc_ctx;
 /* --- pure host helpers (no device needed) */
 int  pmc_abi_version(void);
 const char* pmc_last_error(void);
+/* the compiler and the flags this binary was built with (one line).  Results are bit-compatible with the reference only when the device
+ * code was compiled with -ffp-contract=off (the reference build has no fused multiply-add): pmc_create probes that on the device and
+ * fails with PMC_ERR_DEVICE for a binary built otherwise */
+const char* pmc_build_info(void);
 /* computes the layout of instrument i and returns the total number of doubles of the whole frame buffer */
 int64_t pmc_frame_layout_of(const pmc_scene* scene, int32_t instrument, pmc_frame_layout* out);
 

@@ -20,6 +20,8 @@
 #include <rccl/rccl.h>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -31,26 +33,38 @@
 namespace
 {
     std::mutex g_tuneMutex;
-    std::map<std::string, std::string>& tuneTable()
+    // name -> value; the values live in a pool that is never shrunk, so that a pointer handed out by pmcTune stays valid when another
+    // host thread sets or clears switches meanwhile (one host thread per device drives pmc_create / pmc_run_primary in the CLI and in
+    // the multi-device tests).  A switch is SAMPLED where it is used -- the table layouts at pmc_create, the kernel selection at
+    // pmc_run_primary: changing switches while a context is being created or is running gives that context either value.
+    std::map<std::string, const std::string*>& tuneTable()
     {
-        static std::map<std::string, std::string> table;
+        static std::map<std::string, const std::string*> table;
         return table;
     }
+    const std::string* internTuneValue(const char* value)
+    {
+        static std::deque<std::string> pool;
+        for (const auto& v : pool)
+            if (v == value) return &v;
+        pool.emplace_back(value);
+        return &pool.back();
+    }
 }
-// the value of a tuning switch, or null (the pointer stays valid until the switch is set again or removed)
+// the value of a tuning switch, or null (the pointer stays valid for the life of the process)
 extern "C" const char* pmcTune(const char* name)
 {
     std::lock_guard<std::mutex> lock(g_tuneMutex);
     auto& table = tuneTable();
     auto at = table.find(name);
-    return at == table.end() ? nullptr : at->second.c_str();
+    return at == table.end() ? nullptr : at->second->c_str();
 }
 extern "C" int pmc_tuning_set(const char* name, const char* value)
 {
     if (!name) return PMC_ERR_INVALID;
     std::lock_guard<std::mutex> lock(g_tuneMutex);
     if (value)
-        tuneTable()[name] = value;
+        tuneTable()[name] = internTuneValue(value);
     else
         tuneTable().erase(name);
     return PMC_OK;
@@ -171,6 +185,7 @@ struct pmc_ctx
     pmc_progress_fn progress{nullptr};    // pmc_set_progress
     void* progressUser{nullptr};
     double progressInterval{3.};
+    size_t steppedDownFree{0};            // free device memory when the default pool last stepped down (0: it has not)
     bool slotsConfigured{false};          // the number of slots was set explicitly (PMC_NUM_SLOTS, pmc_set_num_slots)
     bool groupsConfigured{false};         // the number of slot groups was set explicitly (PMC_NUM_GROUPS)
     unsigned long long overflowsSeen{0};  // statistics-list overflows already reported (pmc_run_primary)
@@ -533,8 +548,14 @@ namespace
         // more than half of the free memory the default steps down -- a number the caller has set is taken as it is)
         if (!ctx->slotsConfigured && n > (int64_t(1) << 20) && hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && ctx->plannedBytes > freeBytes / 2)
         {
-            ctx->numSlots = std::max<int64_t>(int64_t(1) << 20, n / 2);
-            return allocateSlots(ctx, ctx->numSlots);
+            // (the requested default, ctx->numSlots, stays as it is: a later segment asks again -- pmc_run_primary -- and gets the larger
+            // pool once the memory is there)
+            const int64_t less = std::max<int64_t>(int64_t(1) << 20, n / 2);
+            fprintf(stderr, "libpmc: device %d has %.1f GB free, %lld packet slots would take %.1f GB: this segment runs with %lld slots (fewer histories in "
+                            "flight, somewhat lower throughput; PMC_NUM_SLOTS / pmc_set_num_slots set the number)\n",
+                    ctx->device, freeBytes * 1e-9, (long long)n, ctx->plannedBytes * 1e-9, (long long)less);
+            ctx->steppedDownFree = freeBytes;
+            return allocateSlots(ctx, less);
         }
         if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && ctx->plannedBytes > freeBytes)
         {
@@ -646,6 +667,51 @@ int pmc_abi_version(void)
     return PMC_ABI_VERSION;
 }
 
+// what this binary was built with (the Makefile hands its HIPFLAGS over): results are bit-compatible with the reference only under
+// -ffp-contract=off (the reference build has no fused multiply-add), and the detector atomics are hardware f64 adds
+// only under -munsafe-fp-atomics
+#define PMC_STRINGIFY2(x) #x
+#define PMC_STRINGIFY(x) PMC_STRINGIFY2(x)
+#ifndef PMC_BUILD_FLAGS
+#define PMC_BUILD_FLAGS "unknown (not built by the Makefile)"
+#endif
+const char* pmc_build_info(void)
+{
+    return "libpmc ABI " PMC_STRINGIFY(PMC_ABI_VERSION) ", gfx950, " __VERSION__ ", flags: " PMC_BUILD_FLAGS
+#if defined(__FP_FAST_FMA) || defined(__FAST_MATH__)
+           " [fast-math macros defined]"
+#endif
+        ;
+}
+
+namespace
+{
+    // a * b + c with run-time operands: 0 when the product is rounded before the sum (-ffp-contract=off), -2^-60 when the compiler fused the two
+    __global__ void contractionProbeKernel(double a, double b, double c, double* out) { out[0] = a * b + c; }
+
+    // one launch per process and device, at the first pmc_create: a binary whose compiler contracted a * b + c computes other last bits than
+    // the reference in every optical depth and exit distance, silently; it is refused instead
+    int checkContraction(int device)
+    {
+        static std::mutex m;
+        static bool checked[64] = {false};
+        std::lock_guard<std::mutex> lock(m);
+        if (device >= 0 && device < 64 && checked[device]) return PMC_OK;
+        double* d = nullptr;
+        double h = 1.;
+        if (hipMalloc(&d, sizeof(double)) != hipSuccess) return fail(PMC_ERR_DEVICE, "hipMalloc failed");
+        hipLaunchKernelGGL(contractionProbeKernel, dim3(1), dim3(1), 0, 0, 1. + 0x1p-30, 1. - 0x1p-30, -1., d);
+        const hipError_t e = hipMemcpy(&h, d, sizeof(double), hipMemcpyDeviceToHost);
+        hipFree(d);
+        if (e != hipSuccess) return hipFail(e, "contraction self-test");
+        if (h != 0.)
+            return fail(PMC_ERR_DEVICE, std::string("this libpmc.so was compiled with floating-point contraction (a * b + c fused): its results would differ from "
+                                                    "the reference's in the last bits everywhere; rebuild with -ffp-contract=off.  ") + pmc_build_info());
+        if (device >= 0 && device < 64) checked[device] = true;
+        return PMC_OK;
+    }
+}
+
 const char* pmc_last_error(void)
 {
     return t_error.c_str();
@@ -695,9 +761,8 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     if (scene->abi_version != PMC_ABI_VERSION) return fail(PMC_ERR_INVALID, "pmc_scene ABI version mismatch");
     if (pmcExperimentBuild())
     {
-        static bool said = false;
-        if (!said) fprintf(stderr, "libpmc: this library was built with an ablation / perturbation macro (a tuning experiment): its results are NOT those of the engine\n");
-        said = true;
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true)) fprintf(stderr, "libpmc: this library was built with an ablation / perturbation macro (a tuning experiment): its results are NOT those of the engine\n");
     }
     if (scene->num_media > PMC_MAX_MEDIA) return fail(PMC_ERR_UNSUPPORTED, "more than PMC_MAX_MEDIA medium components");
     if (scene->num_media > 1 && !scene->media) return fail(PMC_ERR_INVALID, "num_media > 1 without pmc_scene::media");
@@ -713,6 +778,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         return fail(PMC_ERR_DEVICE, "no HIP device available: the MI355X engine cannot run (there is no CPU fallback)");
     if (device < 0 || device >= count) return fail(PMC_ERR_INVALID, "invalid device index");
     HIP_TRY(hipSetDevice(device));
+    if (int rcProbe = checkContraction(device)) return rcProbe;
 
     if (device >= MAX_DEVICES) return fail(PMC_ERR_UNSUPPORTED, "device index beyond the context table");
     pmc_ctx* ctx = new pmc_ctx();
@@ -1513,9 +1579,18 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     HIP_TRY(hipSetDevice(ctx->device));
     DevScene& D = ctx->dev;
     const int64_t want = std::min<int64_t>(ctx->numSlots, (int64_t)std::min<uint64_t>(count, uint64_t(1) << 30));
-    if (want > ctx->allocatedSlots)
+    bool grow = want > ctx->allocatedSlots;
+    if (grow && ctx->allocatedSlots > 0 && ctx->steppedDownFree)
+    {
+        // (a default pool that has stepped down: ask again only when more memory is free than there was then -- not a
+        // reallocation per segment)
+        size_t freeBytes = 0, totalBytes = 0;
+        grow = hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && freeBytes > ctx->steppedDownFree + ctx->steppedDownFree / 4;
+    }
+    if (grow)
     {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->steppedDownFree = 0;
         int rc = allocateSlots(ctx, want);
         if (rc) return rc;
     }
@@ -1656,11 +1731,10 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     if (D.rf_store && D.grid_kind == PMC_GRID_OCTREE && rfParts > pmcRfMaxParts())
     {
         // (a table beyond 2^26 entries: one atomic per contribution, several times slower -- said once, not silently)
-        static bool said = false;
-        if (!said)
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true))
             fprintf(stderr, "libpmc: the radiation field table has %lld entries, more than the log's counting sort partitions (%d x %d): contributions are added atomically\n",
                     (long long)rfKeys, pmcRfMaxParts(), 1 << PMC_RF_BUCKET_BITS);
-        said = true;
     }
     const int rfBuckets = rfLogged ? int(rfParts) : 0;
     const uint32_t rfPadKey = uint32_t(rfBuckets) << PMC_RF_BUCKET_BITS;
@@ -2005,7 +2079,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         if (rfLogged && !initial)
             HIP_TRY(hipMemcpyAsync(ctx->pinned + PMC_MAX_GROUPS + g, ctr + PMC_CTR_RFLOG(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
         if (ctx->progress)
-            HIP_TRY(hipMemcpyAsync(ctx->pinned + 3 * PMC_MAX_GROUPS, ctr + PMC_CTR_HISTORY, sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
+            HIP_TRY(hipMemcpyAsync(ctx->pinned + 3 * PMC_MAX_GROUPS + g, ctr + PMC_CTR_HISTORY, sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
         if (statLogged && !initial && ctx->statCap[g])
             HIP_TRY(hipMemcpyAsync(ctx->pinned + 2 * PMC_MAX_GROUPS + g, ctr + PMC_CTR_STATLOG(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
         return PMC_OK;
@@ -2019,6 +2093,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         return code;
     };
     auto lastReport = std::chrono::steady_clock::now();
+    uint64_t reported = 0;
     auto drive = [&]() -> int {
         for (int g = 0; g < G; ++g)
             if (active[g])
@@ -2069,7 +2144,10 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 if (std::chrono::duration<double>(now - lastReport).count() >= ctx->progressInterval)
                 {
                     lastReport = now;
-                    ctx->progress(ctx->progressUser, std::min<uint64_t>(ctx->pinned[3 * PMC_MAX_GROUPS], count), count);
+                    // (every group copies the cursor into a word of its own, on its own stream; this group's copy is complete -- its
+                    // stream has just been waited for -- and the report never goes backwards: a running maximum)
+                    reported = std::max<uint64_t>(reported, std::min<uint64_t>(ctx->pinned[3 * PMC_MAX_GROUPS + g], count));
+                    ctx->progress(ctx->progressUser, reported, count);
                 }
             }
             if (genDump)

@@ -15,7 +15,7 @@ from .host import CounterValues, FrameLayout
 _LIBDIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 
 # every symbol include/pmc.h and include/pmc_tuning.h declare
-SYMBOLS = ["pmc_abi_version", "pmc_last_error", "pmc_frame_layout_of", "pmc_create", "pmc_destroy", "pmc_bind_frames",
+SYMBOLS = ["pmc_abi_version", "pmc_build_info", "pmc_last_error", "pmc_frame_layout_of", "pmc_create", "pmc_destroy", "pmc_bind_frames",
            "pmc_clear_frames", "pmc_run_primary", "pmc_set_progress", "pmc_sync", "pmc_download", "pmc_frames_device", "pmc_frames_size",
            "pmc_last_kernel_ms", "pmc_counters", "pmc_reset_counters", "pmc_trace_ray", "pmc_set_launch",
            "pmc_set_num_slots", "pmc_last_timing", "pmc_last_walk_timing", "pmc_walk_work", "pmc_radiation_field_size", "pmc_radiation_field_device",
@@ -48,6 +48,7 @@ def lib():
         L = C.CDLL(path)
         L.pmc_abi_version.restype = C.c_int
         L.pmc_last_error.restype = C.c_char_p
+        L.pmc_build_info.restype = C.c_char_p
         L.pmc_frame_layout_of.restype = C.c_int64
         L.pmc_frame_layout_of.argtypes = [C.c_void_p, C.c_int32, C.POINTER(FrameLayout)]
         L.pmc_create.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]

@@ -35,6 +35,13 @@ def test_every_declared_symbol_is_exported(libpmc):
         assert name not in boundary and name in tuning
 
 
+def test_build_info_names_the_flags_that_decide_the_results(libpmc):
+    """the binary says what it was built with; the flags bit-compatibility rests on must be among them (pmc_create also probes the
+    contraction on the device and refuses a binary that fuses a * b + c: every -m gpu test passes through that probe)"""
+    info = libpmc.pmc_build_info().decode()
+    assert "-ffp-contract=off" in info and "-munsafe-fp-atomics" in info and "gfx950" in info and "ABI 9" in info
+
+
 def test_the_library_reads_three_environment_settings_only():
     """experiment switches go through pmc_tuning_set (include/pmc_tuning.h), not through the environment of the process"""
     names = set()
