@@ -85,6 +85,55 @@ def pmc_l2(kernel):
     return None, None
 
 
+KERNEL_RE = (r"(voroPropKernel|voroPeelKernel|walkPeelKernel|walkPropKernel|walkKernel|transitionKernel|launchKernel|cycleStartKernel|endedScanKernel|"
+             r"statMergeKernel|statReduceKernel|peelSortCountKernel|peelSortOffsetsKernel|rfHistKernel|rfScanKernel|rfScatterKernel|rfReduceKernel)")
+WALK_KERNELS = ("walkKernel", "walkPeelKernel", "walkPropKernel", "voroPeelKernel", "voroPropKernel")
+PMC_PASS_PACKETS = 20000000
+# what one unit of FETCH_SIZE / WRITE_SIZE stands for, calibrated on this box class with a KNOWN number of lines from beyond L2
+# (tools/fetch_calibration.sh, profiles/microbench/fetch_calibration_mi355x.txt; profiles/README.md "FETCH_SIZE calibration")
+FETCH_UNIT_BYTES = 1024.0
+
+
+def pmc_in_run(scene_file, passthrough):
+    """Hardware counters of THIS build on THIS box, behind the timed region: one step of PMC_PASS_PACKETS packets of the same workload is run
+    again in a child process under `rocprofv3 --pmc` -- three passes (FETCH_SIZE; WRITE_SIZE; the L2 set), each a run of its own as
+    MI355X_MICROARCH.md prescribes (no trace domain next to --pmc) -- on the scene the timed run has saved (no second set-up).  Returns
+    {kernel: {counter: sum over its launches}} or None when rocprofv3 is not on PATH or a pass fails (the line then falls back to the
+    committed summaries and says so)."""
+    import csv
+    import glob
+    import shutil
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not prof:
+        return None
+    tot = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    for counters in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum SQ_INSTS_VALU SQ_WAVES"):
+        out = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        cmd = [prof, "--pmc"] + counters.split() + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "1", "--warmup", "0", "--packets", str(PMC_PASS_PACKETS), "--no-cpu-baseline", "--no-secondary", "--no-breakdown",
+               "--no-counters", "--scene-file", scene_file] + passthrough
+        try:
+            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, cwd="/tmp", env=env)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                raise RuntimeError("no counter_collection.csv")
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    m = re.search(KERNEL_RE, row["Kernel_Name"])
+                    if m:
+                        k = tot.setdefault(m.group(1), {})
+                        k[row["Counter_Name"]] = k.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+        except Exception as exc:  # noqa: BLE001 - evidence, not the measurement
+            sys.stderr.write(f"[bench] counter pass '{counters}' failed: {exc}\n")
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return tot
+
+
 def cpu_baseline(ski_path=SKI, input_dir=None, packets_per_core=100000):
     """photon packets/s of the CPU path on this box's host cores, on a bounded sample (about 10-30 s)"""
     cores = min(os.cpu_count() or 1, 24)  # the reference caps a process at 24 threads (ParallelFactory.cpp:43-50)
@@ -149,6 +198,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--secondary", action="store_true", help="N > 1: also measure the uniform-box source (default at N = 1)")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-kernel pass (one slot group, kernels in series) behind the timed region")
+    ap.add_argument("--no-counters", action="store_true",
+                    help="skip the hardware-counter passes behind the timed region (one step of 2e7 packets re-run under rocprofv3 --pmc: FETCH_SIZE, "
+                         "WRITE_SIZE, L2 requests / hits / misses; N = 1 only)")
+    ap.add_argument("--scene-file", default=None, help="(internal: the counter passes) load the scene from this file (skh_scene_save) instead of setting it up")
     args = ap.parse_args()
 
     import torch
@@ -218,7 +271,7 @@ def main():
             raise SystemExit("--config 5 selects its own ski file and source")
         args.ski = os.path.join(ROOT, "tests", "ski", "cfg5.ski")
         sitedir = tempfile.mkdtemp(prefix=f"bench_sites_r{rank}_")
-        if rank == 0 or world == 1:
+        if (rank == 0 or world == 1) and not args.scene_file:
             subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_sites.py"), "--n", str(int(args.sites)), "--seed", "1",
                                    os.path.join(sitedir, "cfg5_sites.txt")])
         os.environ["SKH_INPUT_PATH"] = sitedir
@@ -227,7 +280,7 @@ def main():
             raise SystemExit("--config 4 selects its own ski file and source")
         args.ski = os.path.join(ROOT, "tests", "ski", "cfg4.ski")
         sphdir = tempfile.mkdtemp(prefix=f"bench_sph_r{rank}_")
-        if rank == 0 or world == 1:
+        if (rank == 0 or world == 1) and not args.scene_file:
             subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "make_sph.py"), "--n", "1000000", "--seed", "1",
                                    os.path.join(sphdir, "cfg4_sph.txt")])
         os.environ["SKH_INPUT_PATH"] = sphdir
@@ -258,7 +311,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(path, steps, warmup):
+    def measure(path, steps, warmup, save_scene_to=None):
         """sets the scene of ski file `path` up on this rank's GPU and times `steps` segments; returns the numbers of the
         JSON line (rank 0) -- value, roofline inputs, counters"""
         # Every rank needs a replica of the scene.  ONE rank sets it up (all host cores) and saves it as one file in /dev/shm
@@ -266,11 +319,15 @@ def main():
         sim = None
         cache = None
         t_setup = time.perf_counter()
-        if rank == 0:
+        if args.scene_file:
+            sim = SceneFile(args.scene_file)
+        elif rank == 0:
             sim = Simulation(path, num_packets=total_per_step)
             if args.config == 4:
                 sim.use_device_sampler(local_rank)  # setup-time density sampling of the particle medium on this rank's GPU
             sim.setup()
+            if save_scene_to:
+                sim.save_scene(save_scene_to)
             if world > 1:
                 # (a private file under an unpredictable name, readable by this user only; the loader checks sizes, offsets and a
                 # checksum before it trusts a byte of it)
@@ -482,8 +539,14 @@ def main():
             # line-rate evidence for that kernel: its L2 requests / hits / misses from the committed counter pass (2e7 packets of the
             # headline workload), per lane-step of this run's count, and its miss rate against the chip's rate of random lines from
             # beyond L2 (GATHER_NO_LOCALITY: profiles/microbench/true_gather_mi355x.txt) with the kernel's own serial time
-            if args.config == 2 and args.source == "sersic" and not args.store_radiation_field:
-                l2, l2_source = pmc_l2(name)
+            if counters_in_run or (args.config == 2 and args.source == "sersic" and not args.store_radiation_field):
+                l2, l2_source = None, None
+                in_run = False
+                for kname, v in (counters_in_run or {}).items():
+                    if name.startswith(kname) and v.get("TCC_REQ_sum"):
+                        l2, l2_source, in_run = v, f"this run (rocprofv3 --pmc pass over {PMC_PASS_PACKETS} packets behind the timed region)", True
+                if l2 is None and args.config == 2 and args.source == "sersic" and not args.store_radiation_field:
+                    l2, l2_source = pmc_l2(name)
                 if l2 and l2.get("TCC_REQ_sum"):
                     lane_steps_2e7 = (b["prop_lane_steps"] if name == "walkPropKernel" else b["peel_lane_steps"]) * (2e7 / b["packets"])
                     seconds_2e7 = ms * 1e-3 * (2e7 / b["packets"])
@@ -493,7 +556,7 @@ def main():
                         "lines_per_visit": l2["TCC_MISS_sum"] / lane_steps_2e7,
                         "line_rate_frac": l2["TCC_MISS_sum"] / seconds_2e7 / GATHER_NO_LOCALITY,
                         "valu_instructions_per_lane_step": l2["SQ_INSTS_VALU"] / lane_steps_2e7,
-                        "l2_counters_measured_in_run": False, "l2_counters_source": l2_source})
+                        "l2_counters_measured_in_run": in_run, "l2_counters_source": l2_source})
             extra["serial_kernel_ms_per_step"] = {"walkPropKernel": b["prop_ms"] * scale, "walkPeelKernel2": b["peel_ms"] * scale,
                                                   "launch + transition + cycle start + scan": b["transition_side_ms"] * scale,
                                                   "segment": b["segment_ms"] * scale}
@@ -506,7 +569,23 @@ def main():
                 "rewalk_visits_per_packet": m["counters"]["rewalk_visits"] / launches / n,
                 "algorithmic_bytes_per_packet": bytes_per_launch / n, "algorithmic_bytes_per_visit": bytes_per_visit}
 
-    main_run = measure(ski_path, args.steps, args.warmup)
+    # behind the timed region (N = 1): hardware counters of this build on this box -- one step of 2e7 packets re-run under rocprofv3 --pmc on
+    # the scene that the timed run saves
+    counter_scene = None
+    if rank == 0 and world == 1 and not args.no_counters and not args.scene_file:
+        fd, counter_scene = tempfile.mkstemp(prefix="pmc_scene_", suffix=".bin", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        os.close(fd)
+        os.chmod(counter_scene, 0o600)
+    main_run = measure(ski_path, args.steps, args.warmup, save_scene_to=counter_scene)
+    counters_in_run = None
+    if counter_scene:
+        try:
+            passthrough = ["--config", str(args.config)] if args.config != 2 else []
+            if args.config == 5:
+                passthrough += ["--sites", str(args.sites)]
+            counters_in_run = pmc_in_run(counter_scene, passthrough)
+        finally:
+            os.unlink(counter_scene)
     # the second source north_star names, measured in the same run on the same octree (default workload only): three steps
     secondary = None
     if args.config == 2 and args.source == "sersic" and not args.store_radiation_field and args.ski == SKI and not args.no_secondary \
@@ -522,12 +601,27 @@ def main():
 
     if rank == 0:
         roof = roofline_of(main_run)
-        traffic, traffic_all, traffic_source = pmc_traffic(main_run["packets_this_rank"]) if (args.ski == SKI and args.source == "sersic" and args.config == 2) else (None, None, None)
-        roof["traffic"] = traffic
-        roof["traffic_all_kernels"] = traffic_all
-        roof["traffic_measured_in_run"] = False
-        roof["traffic_source"] = (traffic_source + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/run_profile_set.sh) over a step of 2e7 packets, "
-                                  "scaled by the packet count; `traffic` = the walk kernels, `traffic_all_kernels` = every kernel of the step") if traffic_source else None
+        if counters_in_run and any("FETCH_SIZE" in v for v in counters_in_run.values()):
+            # measured behind the timed region of THIS run: FETCH_SIZE + WRITE_SIZE of one step of PMC_PASS_PACKETS packets, scaled by the
+            # packet count (the unit and what a miss moves: FETCH_UNIT_BYTES, profiles/README.md "FETCH_SIZE calibration")
+            scale = FETCH_UNIT_BYTES / PMC_PASS_PACKETS * main_run["packets_this_rank"]
+            per_kernel = {k: (v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * scale for k, v in counters_in_run.items()}
+            roof["traffic"] = sum(b for k, b in per_kernel.items() if k in WALK_KERNELS)
+            roof["traffic_all_kernels"] = sum(per_kernel.values())
+            roof["traffic_measured_in_run"] = True
+            roof["traffic_per_kernel"] = {k: {"fetch": v.get("FETCH_SIZE", 0.0) * scale, "write": v.get("WRITE_SIZE", 0.0) * scale}
+                                          for k, v in sorted(counters_in_run.items()) if "FETCH_SIZE" in v}
+            roof["traffic_over_algorithmic"] = roof["traffic"] / (roof["algorithmic_bytes_per_packet"] * main_run["packets_this_rank"])
+            roof["traffic_source"] = (f"this run: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes (one each) over one step of {PMC_PASS_PACKETS} packets of this "
+                                      "workload behind the timed region, scaled by the packet count; `traffic` = the walk kernels, `traffic_all_kernels` = "
+                                      "every kernel of the step; memory-side (fabric) requests of the L2s: Infinity-Cache hits included")
+        else:
+            traffic, traffic_all, traffic_source = pmc_traffic(main_run["packets_this_rank"]) if (args.ski == SKI and args.source == "sersic" and args.config == 2) else (None, None, None)
+            roof["traffic"] = traffic
+            roof["traffic_all_kernels"] = traffic_all
+            roof["traffic_measured_in_run"] = False
+            roof["traffic_source"] = (traffic_source + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/run_profile_set.sh) over a step of 2e7 packets, "
+                                      "scaled by the packet count; `traffic` = the walk kernels, `traffic_all_kernels` = every kernel of the step") if traffic_source else None
         roof["kernel"] = ("voroPropKernel + voroPeelKernel (Voronoi)" if args.config == 5 else "walkPeelKernel + walkPropKernel (octree)") + \
                          ": all launches of one step, overlapped on the slot groups' streams (denominator: segment_ms)"
         value = total_per_step * args.steps / main_run["elapsed"]

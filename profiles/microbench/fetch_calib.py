@@ -16,6 +16,16 @@ B.bridge_random_table.restype = C.c_void_p
 B.bridge_random_table.argtypes = [C.c_uint32]
 table = B.bridge_random_table(1 << 23)  # 256 MB as 32-byte records
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+if os.environ.get("FETCH_CALIB_STREAMS"):
+    # known byte counts of wide coalesced accesses and of scattered 8-byte stores (fetch_calib.hip)
+    S = C.CDLL(os.path.join(ROOT, "profiles", "microbench", "libfetchcalib.so"))
+    S.fetch_calib_run.argtypes = [C.c_size_t, C.POINTER(C.c_float)]
+    ms = (C.c_float * 3)()
+    nbytes = 1 << 31
+    rc = S.fetch_calib_run(nbytes, ms)
+    print(f"streams over {nbytes} bytes (rc {rc}): read {nbytes / ms[0] / 1e9:.2f} TB/s, write {nbytes / ms[1] / 1e9:.2f} TB/s, "
+          f"scattered 8-byte stores ({nbytes // 64} sectors) {nbytes / 64 / ms[2] / 1e6:.2f}e9 /s")
+    sys.exit(0)
 for loads, records in ((2, 1 << 23), (1, 1 << 24), (2, 1 << 20)):
     # (every call launches chaseTrue twice: 10 warm-up steps, then `steps`)
     r = B.bridge_true_gather(loads, 1, table, records, 256, 768, steps, None)

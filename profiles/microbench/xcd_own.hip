@@ -2,6 +2,8 @@
 // (round-5 review, item 1a.)  The synthetic walker of bridge.hip (one walk per lane on the scene's own CellRec table with its real links,
 // the f64 body of the step, six LDS reads, rounds at `refill` waiting lanes, task loads / result stores) in two modes:
 //   MODE 0  as bridge.hip: every workgroup walks anywhere in the table
+//   MODE 2  the upper bound of MODE 1: the same ownership with hand-overs that cost NOTHING -- a walk that leaves its XCD's eighth is dropped
+//           (and counted), its lane takes a fresh start in its own eighth at the next round: no queue, no record, no atomics
 //   MODE 1  a workgroup reads HW_REG_XCC_ID = x and only ever touches cells of the x-th eighth of the depth-first table (its XCD's L2
 //           then sees 3.8 MB of the 30.5 MB); a walk whose next cell belongs to another eighth is HANDED OVER: the lane writes a 128-byte
 //           state record into the target XCD's queue (write-through `sc0 sc1` stores, a flag word per record behind `s_waitcnt vmcnt(0)`)
@@ -35,6 +37,7 @@ namespace
         int steps, refill;
         uint32_t capLen, tabEntries;
         uint32_t ownerMagic;    // owner(cell) = min(7, umulhi(cell, ownerMagic))
+        unsigned long long zero;
     };
 
     __device__ __forceinline__ uint32_t mix(uint32_t x)
@@ -116,7 +119,12 @@ namespace
             {
                 rounds += 1;
                 // ---- hand-overs of this wave, one claim per target queue
-                if (MODE)
+                if (MODE == 2)
+                {
+                    if (pend) handed += 1;
+                    pend = false;
+                }
+                if (MODE == 1)
                 {
                     unsigned long long pm = __ballot(pend);
                     if (pm)
@@ -152,7 +160,7 @@ namespace
                 const bool want = !active;
                 // ---- handed-over walks of this XCD first
                 unsigned long long took = 0;
-                if (MODE)
+                if (MODE == 1)
                 {
                     const unsigned long long idle = __ballot(want);
                     const int nidle = __popcll(idle);
@@ -160,8 +168,11 @@ namespace
                     int take = 0;
                     if (lane == 0)
                     {
-                        h = __hip_atomic_load(A.qctl + 32 * xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long t = __hip_atomic_load(A.qctl + 32 * xcc + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // (read-modify-write reads: a relaxed agent-scope LOAD is served by this XCD's L2 and returned a stale tail -- the first
+                        // version of this benchmark left 1.2e7 handed-over walks in the queues; atomics execute at the memory side)
+                        // (A.zero is 0 at run time: `atomicAdd(p, 0)` with a literal is folded into an atomic LOAD by the compiler -- and stays stale)
+                        h = atomicAdd(A.qctl + 32 * xcc, A.zero);
+                        const unsigned long long t = atomicAdd(A.qctl + 32 * xcc + 16, A.zero);
                         take = t > h ? (int)min((unsigned long long)nidle, t - h) : 0;
                         if (take && atomicCAS(A.qctl + 32 * xcc, h, h + take) != h) take = 0, failed += 1;
                     }
@@ -173,7 +184,9 @@ namespace
                         const unsigned long long ticket = h + rank;
                         const uint32_t at = (uint32_t)ticket & (A.qcap - 1u);
                         const uint32_t expect = (uint32_t)(ticket / A.qcap) + 1u;
-                        while (loadWT32(A.flags + (size_t)xcc * A.qcap + at) != expect) __builtin_amdgcn_s_sleep(1);
+                        int polls = 0;
+                        while (loadWT32(A.flags + (size_t)xcc * A.qcap + at) != expect && ++polls < 2000) __builtin_amdgcn_s_sleep(1);
+                        if (polls >= 2000) failed += 1000000ull;  // (a record that never arrived: reported, the walk is taken as it is)
                         const uint4* rec = A.queue + ((size_t)xcc * A.qcap + at) * 8u;
                         u32x4 a, b, c, d, e, f, g, hh;
                         asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc0 sc1\n\t"
@@ -299,10 +312,10 @@ namespace
             atomicAdd(A.counters + 2, waveSteps);
             atomicAdd(A.counters + 3, rounds);
             atomicAdd(A.counters + 8 + xcc, laneSteps);
-            atomicAdd(A.counters + 7, failed);
         }
         atomicAdd(A.counters + 4, walks);
         if (handed) atomicAdd(A.counters + 6, handed);
+        if (failed) atomicAdd(A.counters + 7, failed);
         if (sinkD == 1.2345 || sinkU == 0x12345678u) A.counters[5] = 1;
     }
 }
@@ -351,7 +364,7 @@ extern "C" int xcdown_run(int mode, const void* table, uint32_t records, const i
     a.table = reinterpret_cast<const uint4*>(table), a.records = records, a.starts = binned;
     for (int i = 0; i < 9; ++i) a.binOffset[i] = binOffset[i];
     a.queue = queue, a.flags = flags, a.qctl = qctl, a.qcap = qcap, a.slotIn = slotIn, a.slotOut = slotOut, a.slotCap = slotCap, a.counters = counters;
-    a.steps = steps, a.refill = refill, a.capLen = (uint32_t)capLen, a.tabEntries = 1025u, a.ownerMagic = magic;
+    a.steps = steps, a.refill = refill, a.capLen = (uint32_t)capLen, a.tabEntries = 1025u, a.ownerMagic = magic, a.zero = 0ull;
     const size_t ldsBytes = size_t(3) * 1025 * 8;
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
@@ -362,7 +375,9 @@ extern "C" int xcdown_run(int mode, const void* table, uint32_t records, const i
         hipMemset(qctl, 0, 256 * sizeof(unsigned long long));
         hipMemset(counters, 0, 32 * sizeof(unsigned long long));
         hipEventRecord(e0);
-        if (mode)
+        if (mode == 2)
+            hipLaunchKernelGGL(walkOwn<2>, dim3(grid), dim3(block), ldsBytes, 0, b);
+        else if (mode)
             hipLaunchKernelGGL(walkOwn<1>, dim3(grid), dim3(block), ldsBytes, 0, b);
         else
             hipLaunchKernelGGL(walkOwn<0>, dim3(grid), dim3(block), ldsBytes, 0, b);

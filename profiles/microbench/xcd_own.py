@@ -53,13 +53,10 @@ def main():
 
     run("warm-up", 0)
     print("fresh starts per eighth of the table:", [int(out[24 + i]) for i in range(8)])
-    for block in (768, 512):
-        for refill in (40, 24, 8):
-            run(f"no ownership (bridge walker), rounds at {refill}", 0, block, refill)
-            run(f"XCD owns an eighth of the table, hand-over, rounds at {refill}", 1, block, refill)
-    for grid, block in ((512, 384), (512, 256), (1024, 256)):
-        run("no ownership (bridge walker), rounds at 24", 0, block, 24, grid=grid)
-        run("XCD owns an eighth of the table, hand-over, rounds at 24", 1, block, 24, grid=grid)
+    for block, refill in ((768, 40), (768, 24), (512, 24)):
+        run(f"no ownership (bridge walker), rounds at {refill}", 0, block, refill)
+        run(f"XCD owns an eighth of the table, FREE hand-overs (upper bound), rounds at {refill}", 2, block, refill)
+    run("XCD owns an eighth of the table, hand-over queues (one CAS per wave and round), rounds at 40", 1, 768, 40)
 
 
 if __name__ == "__main__":

@@ -873,6 +873,33 @@ namespace skh
             sites.resize(numSites);
             for (int m = 0; m != numSites; ++m) sites[m] = random.position(extent);
         }
+        else if (policy == "CentralPeak")
+        {
+            // VoronoiMeshSpatialGrid.cpp:67-82: the first site stays at the origin, the others follow a 1/r distribution down to
+            // 1/1000 of the domain's largest radius, in isotropic directions; positions outside the domain are drawn again
+            const int a = 1000;
+            const double rscale = std::sqrt(extent.xmax * extent.xmax + extent.ymax * extent.ymax + extent.zmax * extent.zmax);
+            sites.assign(numSites, Vec3{0., 0., 0.});
+            for (int m = 1; m < numSites;)
+            {
+                const double r = rscale * std::pow(1. / a, random.uniform());
+                const Vec3 k = random.direction();
+                const Vec3 p{r * k.x, r * k.y, r * k.z};
+                if (extent.contains(p.x, p.y, p.z)) sites[m++] = p;
+            }
+        }
+        else if (policy == "ImportedSites")
+        {
+            // VoronoiMeshSpatialGrid.cpp:127-132: the positions of the entities of the first imported medium component
+            // (MediumSystem::interface<SiteListInterface>; ImportedMedium.cpp:268-278), in file order
+            const ParticleMedium* imported = dynamic_cast<const ParticleMedium*>(&medium);
+            if (!imported)
+                if (const CompositeMedium* all = dynamic_cast<const CompositeMedium*>(&medium))
+                    for (const Medium* part : all->parts)
+                        if (!imported) imported = dynamic_cast<const ParticleMedium*>(part);
+            if (!imported) throw std::runtime_error("VoronoiMeshSpatialGrid policy ImportedSites: no medium component offers a list of sites (an imported medium)");
+            sites = imported->snapshot.sitePositions();
+        }
         else
         {
             // VoronoiMeshSnapshot.cpp:408-417

@@ -352,9 +352,12 @@ namespace skh
         // ParticleSnapshot::readAndClose (ParticleSnapshot.cpp:79-151)
         _pv.clear();
         _pv.reserve(rows.size());
+        _sites.clear();
+        _sites.reserve(rows.size());
         double sumImported = 0, sumMetallic = 0, sumEffective = 0;
         for (const Array& prop : rows)
         {
+            _sites.push_back(Vec3{prop[0], prop[1], prop[2]});  // (every imported row: ParticleSnapshot::position(m), ParticleSnapshot.cpp:286-289)
             if (useTemperatureCutoff && prop[temperatureIndex] > maxTemperature) continue;
             if (prop[massIndex] == 0.) continue;
             double imported = prop[massIndex];

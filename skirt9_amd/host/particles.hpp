@@ -99,10 +99,14 @@ namespace skh
         size_t numParticles() const { return _pv.size(); }
         const BoxSearch& search() const { return _search; }
         const std::vector<Particle>& particles() const { return _pv; }
+        // the positions of ALL imported entities in file order, also those that carry no mass (SiteListInterface of ImportedMedium,
+        // ImportedMedium.cpp:268-278: the sites of a Voronoi grid with the ImportedSites policy)
+        const std::vector<Vec3>& sitePositions() const { return _sites; }
         const SmoothingKernel& kernel() const { return *_kernel; }
 
     private:
         std::vector<Particle> _pv;
+        std::vector<Vec3> _sites;
         BoxSearch _search;
         std::unique_ptr<SmoothingKernel> _kernel;
         double _mass{0};

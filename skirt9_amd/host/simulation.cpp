@@ -608,11 +608,13 @@ namespace skh
         }
         else if (ge->name == "VoronoiMeshSpatialGrid")
         {
-            // VoronoiMeshSpatialGrid.hpp: policies Uniform (random sites) and File (sites from a column text file)
+            // VoronoiMeshSpatialGrid.hpp: policies Uniform (random sites), CentralPeak, DustDensity, File (sites from a column text file),
+            // ImportedSites (the positions of an imported medium's entities)
             auto grid = std::make_unique<VoronoiSpatialGrid>();
             grid->extent = extent;
             grid->policy = ge->attr("policy", "DustDensity");
-            if (grid->policy != "Uniform" && grid->policy != "File" && grid->policy != "DustDensity")
+            if (grid->policy != "Uniform" && grid->policy != "File" && grid->policy != "DustDensity" && grid->policy != "CentralPeak"
+                && grid->policy != "ImportedSites")
                 unsupported("Voronoi site policy " + grid->policy);
             grid->numSites = rd.integer(*ge, "numSites", 500);
             if (grid->policy == "File")

@@ -45,6 +45,7 @@ Fixtures:
                thread; the two SED files as written, and every FITS frame (flux components, statistics w^0 .. w^4) summed over
                8 x 8 blocks of the 512^2 pixels in double precision (the ten 1 MB FITS files themselves are not committed)
   cfg5dd_cells.npz   the same grid with its sites drawn from the dust density (policy DustDensity): volumes, densities
+  cfg5peak_*, cfg5imp_*   Voronoi site policies CentralPeak and ImportedSites (tests/ski/cfg5peak.ski, cfg5imp.ski): 40 rays and the cell table
   cfg4small_*  reduced config 4 (tests/ski/cfg4small.ski): dust imported from 3000 smoothed particles
                (tests/ski/cfg4small_sph.txt, made by tools/make_sph.py), 2x10^4 packets -> files, rays, cells
   *_rays.txt / *_rays_ref.txt   fixed rays and the reference's (m, ds) sequences (C99 hex floats)
@@ -142,7 +143,7 @@ def main():
         sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
     for name, scale in (("cfg1", 3.08567758e16), ("cfg1mesh", 3.08567758e16), ("cfg1mesh2", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg2deep", 300 * 3.08567758e16), ("cfg2deeper", 100 * 3.08567758e16), ("cfg3small", None), ("cfg3z", None), ("cfg1nf", None), ("cfg2nf", None),
                         ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1sed", None), ("cfg3sed", None), ("cfg3norm", "sed"), ("cfg3disk", "sed"), ("cfg3multi", "sed"), ("cfg3ten", "sed"), ("cfg3flat", "sed"), ("cfg3off", "sed"), ("cfg3plum", "sed"), ("cfg1rf", "rf"), ("cfg3rf", "rf"), ("cfg2ea", None), ("cfg1nfea", None), ("cfg1rfea", "rf"), ("cfg2mm", None), ("cfg2mmea", None), ("cfg1mmnf", None), ("cfg3mm", None), ("cfg1mmrf", "rf"), ("cfg1con", None), ("cfg1netzer", None), ("cfg1laser", None), ("cfg2agn", None), ("cfg1nomed", None),
-                        ("cfg5small", 4000 * 3.08567758e16), ("cfg5dd", "cells"), ("cfg2shell", "cells"), ("cfg2torus", "cells"), ("cfg2ring", "cells"), ("cfg1list", "cells")):
+                        ("cfg5small", 4000 * 3.08567758e16), ("cfg5dd", "cells"), ("cfg5peak", "cellrays"), ("cfg5imp", "cellrays"), ("cfg2shell", "cells"), ("cfg2torus", "cells"), ("cfg2ring", "cells"), ("cfg1list", "cells")):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         ski = os.path.join(ROOT, "tests", "ski", name + ".ski")
@@ -180,9 +181,12 @@ def main():
                     elif f.endswith("_sed.dat"):
                         shutil.copy(os.path.join(tmp, f), os.path.join(HERE, f))
                 continue
-            for f in sorted(os.listdir(tmp)):
-                if f.endswith(".fits") or f.endswith(".dat"):
-                    shutil.copy(os.path.join(tmp, f), os.path.join(HERE, f))
+            if scale == "cellrays":
+                scale = 4000 * 3.08567758e16  # (further Voronoi site policies: the ray dump and the cell table only, no output files)
+            else:
+                for f in sorted(os.listdir(tmp)):
+                    if f.endswith(".fits") or f.endswith(".dat"):
+                        shutil.copy(os.path.join(tmp, f), os.path.join(HERE, f))
             if scale is None:
                 continue  # grids of the same kinds as above: no separate ray / cell fixtures
             # rays: directions are written as hex floats so that both sides parse identical doubles

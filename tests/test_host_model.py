@@ -292,6 +292,19 @@ def test_voronoi_sites_from_the_dust_density():
     assert np.allclose(dens, gold["density"], rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("name,cells", [("cfg5peak", 1500), ("cfg5imp", 3000)])
+def test_voronoi_site_policies(name, cells):
+    """VoronoiMeshSpatialGrid policies CentralPeak (VoronoiMeshSpatialGrid.cpp:67-82: sites from the simulation's random stream, 1/r
+    towards the origin) and ImportedSites (:127-132: the positions of the imported medium's entities, ImportedMedium.cpp:268-278): the
+    same sites as the reference -- its cells carry the reference's volumes and sampled densities (to rounding: own tessellation)"""
+    sim = Simulation(ski(name + ".ski")).setup()
+    gold = np.load(golden(name + "_cells.npz"))
+    head = scene_head(sim)
+    assert head.grid.kind == 3 and head.grid.num_cells == len(gold["density"]) == cells
+    dens = np.ctypeslib.as_array(head.medium.number_density, shape=(cells,))
+    assert np.allclose(dens, gold["density"], rtol=1e-12, atol=0)
+
+
 @pytest.mark.parametrize("name", ["cfg2shell", "cfg2torus", "cfg2ring"])
 def test_more_medium_geometries_bit_exact(name):
     """ShellGeometry, TorusGeometry and RingGeometry as the dust distribution (density, column density for the optical
