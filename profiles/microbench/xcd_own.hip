@@ -77,7 +77,7 @@ namespace
         return v;
     }
 
-    template<int MODE> __global__ __launch_bounds__(768) void walkOwn(const Args A)
+    template<int MODE> __global__ __launch_bounds__(1024) void walkOwn(const Args A)
     {
         extern __shared__ double lds[];
         const int tid = threadIdx.x, lane = tid & 63, block = blockDim.x;

@@ -53,10 +53,11 @@ def main():
 
     run("warm-up", 0)
     print("fresh starts per eighth of the table:", [int(out[24 + i]) for i in range(8)])
-    for block, refill in ((768, 40), (768, 24), (512, 24)):
-        run(f"no ownership (bridge walker), rounds at {refill}", 0, block, refill)
-        run(f"XCD owns an eighth of the table, FREE hand-overs (upper bound), rounds at {refill}", 2, block, refill)
-    run("XCD owns an eighth of the table, hand-over queues (one CAS per wave and round), rounds at 40", 1, 768, 40)
+    for block, refill, grid in ((768, 40, 256), (768, 24, 256), (512, 24, 256), (1024, 24, 256), (1024, 40, 256), (512, 24, 512), (256, 24, 1024)):
+        run(f"no ownership (bridge walker), rounds at {refill}", 0, block, refill, grid=grid)
+        run(f"XCD owns an eighth of the table, FREE hand-overs (upper bound), rounds at {refill}", 2, block, refill, grid=grid)
+    if os.environ.get("XCD_OWN_QUEUES"):
+        run("XCD owns an eighth of the table, hand-over queues (one CAS per wave and round), rounds at 40", 1, 768, 40)
 
 
 if __name__ == "__main__":
