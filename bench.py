@@ -48,11 +48,12 @@ GATHER_L2_RESIDENT = 2.5e11
 def pmc_traffic(packets_per_step):
     """(bytes of the walk kernels, bytes of all kernels, source file) -- memory-side bytes of one step, from the newest committed PMC summary
     profiles/r*_pmc_hbm.csv: FETCH_SIZE + WRITE_SIZE (KiB, separate rocprofv3 --pmc passes over one step of 2e7
-    packets of this workload; tools/run_profile_set.sh, tools/pmc_hbm_summary.py), scaled by the packet count.  The
-    kernel's reads are 16-byte gathers (64-byte fabric requests), so the gfx950 x2 correction for wide coalesced
-    reads (MI355X_MICROARCH.md, HBM) does not apply -- calibrated on this access pattern: the random-gather microbenchmark
-    sustains 2.4e11 gathers/s on a 64 MB table (profiles/microbench/gather_ceiling_mi355x.txt), 15 TB/s at 64 bytes per L2
-    miss; at 128 bytes per miss it would be twice the Infinity Cache's bandwidth.  Infinity-Cache hits are included in the counter."""
+    packets of this workload; tools/run_profile_set.sh, tools/pmc_hbm_summary.py), scaled by the packet count -- the FALLBACK when the
+    counter passes of the run itself (pmc_in_run) are not available.  What the counters count (calibrated in round 6 on known access
+    patterns, profiles/microbench/fetch_calibration_mi355x.txt): a 16-byte gather that misses L2 is ONE 64-byte request to the fabric and
+    FETCH_SIZE counts 64 bytes for it; a wide coalesced read goes out as 128-byte requests that FETCH_SIZE counts at 64 (half the bytes:
+    MI355X_MICROARCH.md); a coalesced write is counted in full, a scattered 8-byte store as one 32-byte request.  The walk kernels' reads are
+    gathers, so their figure stands as counted; Infinity-Cache hits are included."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.csv")),
@@ -612,6 +613,10 @@ def main():
             roof["traffic_per_kernel"] = {k: {"fetch": v.get("FETCH_SIZE", 0.0) * scale, "write": v.get("WRITE_SIZE", 0.0) * scale}
                                           for k, v in sorted(counters_in_run.items()) if "FETCH_SIZE" in v}
             roof["traffic_over_algorithmic"] = roof["traffic"] / (roof["algorithmic_bytes_per_packet"] * main_run["packets_this_rank"])
+            # the other kernels (transition side, sorts, logs) read in wide coalesced streams, which FETCH_SIZE counts at HALF their bytes
+            # (fetch_calibration_mi355x.txt: 0.500 per byte): their bytes with that correction, next to the figure as counted
+            roof["traffic_other_kernels_fetch_doubled"] = sum((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * scale
+                                                              for k, v in counters_in_run.items() if k not in WALK_KERNELS)
             roof["traffic_source"] = (f"this run: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes (one each) over one step of {PMC_PASS_PACKETS} packets of this "
                                       "workload behind the timed region, scaled by the packet count; `traffic` = the walk kernels, `traffic_all_kernels` = "
                                       "every kernel of the step; memory-side (fabric) requests of the L2s: Infinity-Cache hits included")
@@ -622,6 +627,14 @@ def main():
             roof["traffic_measured_in_run"] = False
             roof["traffic_source"] = (traffic_source + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/run_profile_set.sh) over a step of 2e7 packets, "
                                       "scaled by the packet count; `traffic` = the walk kernels, `traffic_all_kernels` = every kernel of the step") if traffic_source else None
+        if counters_in_run:
+            # every walk kernel's L2 picture from the same passes: requests, the share that missed, and the 64-byte requests to the fabric (a gather
+            # that misses is ONE such request: profiles/microbench/fetch_calibration_mi355x.txt) -- `frac` prices algorithmic bytes against the HBM
+            # peak whether the kernel's lines come from HBM, from the Infinity Cache or (l2_miss_frac small) from L2
+            roof["walk_kernels_l2"] = {k: {"l2_requests": v["TCC_REQ_sum"] * main_run["packets_this_rank"] / PMC_PASS_PACKETS,
+                                           "l2_miss_frac": v.get("TCC_MISS_sum", 0.0) / v["TCC_REQ_sum"],
+                                           "valu_instructions": v.get("SQ_INSTS_VALU", 0.0) * main_run["packets_this_rank"] / PMC_PASS_PACKETS}
+                                       for k, v in sorted(counters_in_run.items()) if k in WALK_KERNELS and v.get("TCC_REQ_sum")}
         roof["kernel"] = ("voroPropKernel + voroPeelKernel (Voronoi)" if args.config == 5 else "walkPeelKernel + walkPropKernel (octree)") + \
                          ": all launches of one step, overlapped on the slot groups' streams (denominator: segment_ms)"
         value = total_per_step * args.steps / main_run["elapsed"]
