@@ -54,7 +54,7 @@ extern "C" hipError_t pmcLaunchPeelSortCounts(int slot, int slotBase, int numSlo
 extern "C" size_t pmcRfTempBytes(int numParts);
 extern "C" int pmcRfMaxParts();
 extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, const int* list, int listLen, int maxBlocks,
-                                          size_t ldsBytes, const StatLogArgs* statLog, hipStream_t stream);
+                                          size_t ldsBytes, const StatLogArgs* statLog, uint64_t count, uint64_t keep, hipStream_t stream);
 extern "C" hipError_t pmcLaunchLaunch(int slot, int slotBase, int numSlots, int group, uint64_t first, uint64_t count, uint64_t seed, int initial,
                                       int maxBlocks, size_t ldsBytes, const StatLogArgs* statLog, hipStream_t stream);
 extern "C" hipError_t pmcLaunchStatFlush(int slot, const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n,

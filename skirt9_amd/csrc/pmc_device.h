@@ -481,6 +481,8 @@ struct PeelSortedArgs  // peel-off kernel; rec == nullptr: task records from Tas
                                                    // flushed when it has filled up, pmc_api.hip)
 // per slot group g: offset of the first history the group's ended slots take up this generation (endedScanKernel)
 #define PMC_CTR_HBASE(g) (120 + (g))
+// ... and the first history index the group may not take (the staggered end of a segment: endedScanKernel)
+#define PMC_CTR_HLIMIT(g) (124 + (g))
 #define PMC_MAX_GROUPS 4
 // per slot group g: free blocks of the group's share of the statistics pool (DevScene::stat_pool_free)
 #define PMC_CTR_STATFREE(g) (48 + (g))

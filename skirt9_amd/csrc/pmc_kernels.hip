@@ -616,7 +616,7 @@ extern "C" hipError_t pmcLaunchStatMerge(int slot, int blocks, hipStream_t strea
 // transitions of the slots [slotBase, slotBase + numSlots) of slot group `group`, followed by the scan of the group's
 // ended-history counts (the launch kernel's history indices)
 extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, int group, uint64_t seed, const int* list, int listLen, int maxBlocks,
-                                          size_t ldsBytes, const StatLogArgs* statLog, hipStream_t stream)
+                                          size_t ldsBytes, const StatLogArgs* statLog, uint64_t count, uint64_t keep, hipStream_t stream)
 {
     const StatLogArgs none = {nullptr, nullptr, 0ull, 0, nullptr, nullptr, nullptr};
     const int block = PMC_TRANSITION_BLOCK;
@@ -625,7 +625,8 @@ extern "C" hipError_t pmcLaunchTransition(int slot, int slotBase, int numSlots, 
     hipLaunchKernelGGL(transitionKernel, dim3(grid), dim3(block), ldsBytes, stream, slot, slotBase, numSlots, group, seed, list, listLen, statLog ? *statLog : none);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || list) return e;  // (a sparse generation retires its ended histories in the transition kernel)
-    hipLaunchKernelGGL(endedScanKernel, dim3(1), dim3(PMC_SCAN_THREADS), 0, stream, slot, slotBase, numSlots, group);
+    hipLaunchKernelGGL(endedScanKernel, dim3(1), dim3(PMC_SCAN_THREADS), 0, stream, slot, slotBase, numSlots, group, (unsigned long long)count,
+                       (unsigned long long)keep);
     return hipGetLastError();
 }
 

@@ -178,6 +178,9 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     unsigned long long* ctr = D.counters;
     float walkMs = 0, transMs = 0, peelMs = 0, propMs = 0;
     const bool serialWalks = pmcTune("PMC_SERIAL_WALKS") != nullptr;  // tuning aid: peel-off and propagation kernels one after the other
+    // staggered end of a segment (endedScanKernel): slot group g stops taking histories when fewer than g * drainKeep are left
+    uint64_t drainKeep = 0;
+    if (const char* env = pmcTune("PMC_DRAIN_KEEP")) drainKeep = (uint64_t)std::max(0.0, atof(env));
     const bool genDump = pmcTune("PMC_GEN_DUMP") != nullptr;  // tuning aid: live slots and kernel times of every generation
     int generations = 0;
     // ---- slot groups: group g owns the slots [base[g], base[g] + size[g]) and the stream groupStream[g].  The
@@ -610,7 +613,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             HIP_TRY(hipEventRecord(ctx->evB[g], sg));
             HIP_TRY(hipMemsetAsync(ctr + PMC_CTR_LIVE(g), 0, sizeof(unsigned long long), sg));
             const StatLogArgs statLog = statLogOf(g);
-            HIP_TRY(pmcLaunchTransition(ctx->slot, base[g], size[g], g, seed, listIn, listLen, transitionBlocks, ctx->transitionLds, &statLog, sg));
+            HIP_TRY(pmcLaunchTransition(ctx->slot, base[g], size[g], g, seed, listIn, listLen, transitionBlocks, ctx->transitionLds, &statLog, count,
+                                        drainKeep * uint64_t(g), sg));
             if (!listIn) HIP_TRY(pmcLaunchLaunch(ctx->slot, base[g], size[g], g, first, count, seed, 0, launchBlocks, ctx->launchLds, &statLog, sg));
         }
         else
@@ -665,6 +669,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         return code;
     };
     auto lastReport = std::chrono::steady_clock::now();
+    const auto segmentStart = lastReport;
     uint64_t reported = 0;
     auto drive = [&]() -> int {
         for (int g = 0; g < G; ++g)
@@ -723,8 +728,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                 }
             }
             if (genDump)
-                fprintf(stderr, "PMC_GEN %d group %d live %llu walk_ms %.3f transition_ms %.3f\n", generations, g, ctx->pinned[g],
-                        haveWalk[g] ? walkOfGen : 0.f, ms);
+                fprintf(stderr, "PMC_GEN %d group %d live %llu walk_ms %.3f transition_ms %.3f at_ms %.3f\n", generations, g, ctx->pinned[g],
+                        haveWalk[g] ? walkOfGen : 0.f, ms, 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - segmentStart).count());
             int rc = enqueue(g, false);
             if (rc) return rc;
         }
