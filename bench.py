@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--store-radiation-field", action="store_true",
                     help="run the same workload with RadiationFieldOptions storeRadiationField=true (the RF flavour of the "
                          "walk kernel: one exp, one lnmean and one f64 atomic more per path segment); not the headline number")
+    ap.add_argument("--explicit-absorption", action="store_true",
+                    help="run the same workload with PhotonPacketOptions explicitAbsorption=true (the EA flavour of the propagation kernels); not the headline number")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --packets is the TOTAL per step, split over the ranks by history range (e.g. "
                          "--config 4 --packets 1e9 --gpus 8 = BASELINE configs[3]); default: weak scaling, --packets per GPU")
@@ -302,8 +304,20 @@ def main():
         if 'storeRadiationField="false"' not in text:
             raise SystemExit("--store-radiation-field: the ski file has no storeRadiationField=\"false\" to switch")
         rf_ski = os.path.join(tempfile.mkdtemp(prefix=f"bench_rf_r{rank}_"), os.path.basename(ski_path))
+        if '<RadiationFieldOptions storeRadiationField="false"/>' in text:
+            # (a ski file without a radiation field wavelength grid: the instruments' range in twenty bins)
+            text = text.replace('<RadiationFieldOptions storeRadiationField="false"/>',
+                                '<RadiationFieldOptions storeRadiationField="true"><radiationFieldWLG type="DisjointWavelengthGrid"><LogWavelengthGrid '
+                                'minWavelength="0.1 micron" maxWavelength="10 micron" numWavelengths="20"/></radiationFieldWLG></RadiationFieldOptions>')
         open(rf_ski, "w").write(text.replace('storeRadiationField="false"', 'storeRadiationField="true"'))
         ski_path = rf_ski
+    if args.explicit_absorption:
+        text = open(ski_path).read()
+        if 'explicitAbsorption="false"' not in text:
+            raise SystemExit("--explicit-absorption: the ski file has no explicitAbsorption=\"false\" to switch")
+        ea_ski = os.path.join(tempfile.mkdtemp(prefix=f"bench_ea_r{rank}_"), os.path.basename(ski_path))
+        open(ea_ski, "w").write(text.replace('explicitAbsorption="false"', 'explicitAbsorption="true"'))
+        ski_path = ea_ski
     from skirt9_amd.engine import history_range
     from skirt9_amd.host import scene_head
 
@@ -540,13 +554,13 @@ def main():
             # line-rate evidence for that kernel: its L2 requests / hits / misses from the committed counter pass (2e7 packets of the
             # headline workload), per lane-step of this run's count, and its miss rate against the chip's rate of random lines from
             # beyond L2 (GATHER_NO_LOCALITY: profiles/microbench/true_gather_mi355x.txt) with the kernel's own serial time
-            if counters_in_run or (args.config == 2 and args.source == "sersic" and not args.store_radiation_field):
+            if counters_in_run or (args.config == 2 and args.source == "sersic" and not args.store_radiation_field and not args.explicit_absorption):
                 l2, l2_source = None, None
                 in_run = False
                 for kname, v in (counters_in_run or {}).items():
                     if name.startswith(kname) and v.get("TCC_REQ_sum"):
                         l2, l2_source, in_run = v, f"this run (rocprofv3 --pmc pass over {PMC_PASS_PACKETS} packets behind the timed region)", True
-                if l2 is None and args.config == 2 and args.source == "sersic" and not args.store_radiation_field:
+                if l2 is None and args.config == 2 and args.source == "sersic" and not args.store_radiation_field and not args.explicit_absorption:
                     l2, l2_source = pmc_l2(name)
                 if l2 and l2.get("TCC_REQ_sum"):
                     lane_steps_2e7 = (b["prop_lane_steps"] if name == "walkPropKernel" else b["peel_lane_steps"]) * (2e7 / b["packets"])
@@ -589,7 +603,7 @@ def main():
             os.unlink(counter_scene)
     # the second source north_star names, measured in the same run on the same octree (default workload only): three steps
     secondary = None
-    if args.config == 2 and args.source == "sersic" and not args.store_radiation_field and args.ski == SKI and not args.no_secondary \
+    if args.config == 2 and args.source == "sersic" and not args.store_radiation_field and not args.explicit_absorption and args.ski == SKI and not args.no_secondary \
             and (world == 1 or args.secondary):
         text = open(SKI).read()
         new = ('<UniformBoxGeometry minX="-10000 pc" maxX="10000 pc" minY="-10000 pc" maxY="10000 pc" '
@@ -669,6 +683,7 @@ def main():
                        "packets_per_step_per_gpu": total_per_step / world,
                        "cells": main_run["cells"],
                        "store_radiation_field": bool(args.store_radiation_field),
+                       "explicit_absorption": bool(args.explicit_absorption),
                        "parallelism": f"history-range x{world}"},
             "roofline": roof,
         }

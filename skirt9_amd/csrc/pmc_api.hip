@@ -264,11 +264,9 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
     D.force_scattering = scene->options.force_scattering;
     D.voro_prop_checkpoints = pmcTune("PMC_PROP_NO_CHECKPOINTS") == nullptr ? 1 : 0;
     // (bit 0: peel-off walks of voroPeelKernel, bit 1: propagation walks of voroPropKernel)
-    D.voro_defer_scan = (scene->grid.kind == PMC_GRID_VORONOI && scene->num_media <= 1 && pmcTune("PMC_VORO_NO_PEEL_KERNEL") == nullptr
+    D.voro_defer_scan = (scene->grid.kind == PMC_GRID_VORONOI && pmcTune("PMC_VORO_NO_PEEL_KERNEL") == nullptr
                          && pmcTune("PMC_VORO_NO_DEFERRED_SCAN") == nullptr) ? 1 : 0;
-    if (scene->grid.kind == PMC_GRID_VORONOI && D.vgen_run && !scene->radiation_field.store && !scene->options.explicit_absorption
-        && pmcTune("PMC_VORO_NO_DEFERRED_SCAN") == nullptr)
-        D.voro_defer_scan |= 2;
+    if (scene->grid.kind == PMC_GRID_VORONOI && D.vgen_run && pmcTune("PMC_VORO_NO_DEFERRED_SCAN") == nullptr) D.voro_defer_scan |= 2;
     D.min_weight_reduction = scene->options.min_weight_reduction;
     D.min_scatt_events = scene->options.min_scatt_events;
     D.path_length_bias = scene->options.path_length_bias;

@@ -37,10 +37,10 @@ extern "C" hipError_t pmcLaunchPeel(int slot, int wide, int slotBase, int numSlo
                                     const PeelRec* sortedRec, const unsigned long long* sortedCount, unsigned long long* xcdCursor, hipStream_t stream);
 extern "C" int pmcVoroPropWavesPerSimd(void);
 extern "C" hipError_t pmcLaunchVoroProp(int slot, const int32_t* list, const unsigned long long* count, unsigned long long* xcdCursor, int segments, uint64_t seed,
-                                        int grid, hipStream_t stream);
+                                        int flavour, int grid, hipStream_t stream);
 extern "C" int pmcVoroPeelWavesPerSimd(void);
 extern "C" hipError_t pmcLaunchVoroPeel(int slot, int rec, int tab, const int32_t* list, const unsigned long long* count, unsigned long long* xcdCursor, int segments,
-                                        int grid, hipStream_t stream);
+                                        int severalMedia, int grid, hipStream_t stream);
 extern "C" hipError_t pmcLaunchProp(int slot, int wide, int storeRf, int slotBase, int numSlots, const int* list, int cursor, uint64_t seed, int grid,
                                     size_t ldsBytes, const RfLogArgs* rfLog, hipStream_t stream);
 extern "C" hipError_t pmcLaunchRfFlush(int slot, const uint32_t* keys, const double* vals, uint32_t* sortedKeys, double* sortedVals, unsigned long long n,

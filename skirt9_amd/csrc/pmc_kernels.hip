@@ -447,18 +447,35 @@ extern "C" hipError_t pmcLaunchWalk(int slot, int gridKind, int storeRf, int tas
 // runs is DevScene::vobs_run[tab]; xcdCursor: `segments` (8 or 1) zeroed cursors over equal parts of the list
 extern "C" int pmcVoroPeelWavesPerSimd(void) { return PMC_VPEEL_MIN_WAVES; }
 extern "C" hipError_t pmcLaunchVoroPeel(int slot, int rec, int tab, const int32_t* list, const unsigned long long* count, unsigned long long* xcdCursor, int segments,
-                                        int grid, hipStream_t stream)
+                                        int severalMedia, int grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL(voroPeelKernel, dim3(grid), dim3(256), 0, stream, slot, rec, tab, list, count, xcdCursor, segments);
+    if (severalMedia)
+        hipLaunchKernelGGL(voroPeelKernel<true>, dim3(grid), dim3(256), 0, stream, slot, rec, tab, list, count, xcdCursor, segments);
+    else
+        hipLaunchKernelGGL(voroPeelKernel<false>, dim3(grid), dim3(256), 0, stream, slot, rec, tab, list, count, xcdCursor, segments);
     return hipGetLastError();
 }
 
 // Voronoi: the propagation walks (task record 0) of the slots in `list` on the table of runs DevScene::vgen_run
 extern "C" int pmcVoroPropWavesPerSimd(void) { return PMC_VPROP_MIN_WAVES; }
+// flavour: bit 0 radiation field, bit 1 explicit absorption, bit 2 several medium components
 extern "C" hipError_t pmcLaunchVoroProp(int slot, const int32_t* list, const unsigned long long* count, unsigned long long* xcdCursor, int segments, uint64_t seed,
-                                        int grid, hipStream_t stream)
+                                        int flavour, int grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL(voroPropKernel, dim3(grid), dim3(256), 0, stream, slot, list, count, xcdCursor, segments, seed);
+#define PMC_VPROP_CASE(f, RF, EA, MM) \
+    case f: hipLaunchKernelGGL((voroPropKernel<RF, EA, MM>), dim3(grid), dim3(256), 0, stream, slot, list, count, xcdCursor, segments, seed); break;
+    switch (flavour & 7)
+    {
+        PMC_VPROP_CASE(0, false, false, false)
+        PMC_VPROP_CASE(1, true, false, false)
+        PMC_VPROP_CASE(2, false, true, false)
+        PMC_VPROP_CASE(3, true, true, false)
+        PMC_VPROP_CASE(4, false, false, true)
+        PMC_VPROP_CASE(5, true, false, true)
+        PMC_VPROP_CASE(6, false, true, true)
+        PMC_VPROP_CASE(7, true, true, true)
+    }
+#undef PMC_VPROP_CASE
     return hipGetLastError();
 }
 

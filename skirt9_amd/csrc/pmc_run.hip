@@ -222,10 +222,10 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     const unsigned long long* const zeroCount = ctx->xcdCursors + size_t(PMC_MAX_GROUPS) * (PMC_SORT_OBS + 1) * 8;
     // Voronoi, one medium component: the peel-off walks towards an observer that has a table of runs go through a kernel of their own
     // (a switch set after pmc_create: the generic kernel knows a walk whose first cell is still to be scanned as well)
-    const bool voroPeelKernels = D.grid_kind == PMC_GRID_VORONOI && D.num_media <= 1 && pmcTune("PMC_VORO_NO_PEEL_KERNEL") == nullptr;
-    // ... and the propagation walks of the plain flavour, on the table of runs with all neighbours (when pmc_create built it)
-    const bool voroPropKernel = D.grid_kind == PMC_GRID_VORONOI && D.num_media <= 1 && D.vgen_run && !D.rf_store && !D.explicit_absorption
-                                && pmcTune("PMC_VORO_NO_PROP_KERNEL") == nullptr;
+    const bool voroPeelKernels = D.grid_kind == PMC_GRID_VORONOI && pmcTune("PMC_VORO_NO_PEEL_KERNEL") == nullptr;
+    // ... and the propagation walks (every flavour since round 6), on the table of runs with all neighbours (when pmc_create built it)
+    const bool voroPropKernel = D.grid_kind == PMC_GRID_VORONOI && D.vgen_run && pmcTune("PMC_VORO_NO_PROP_KERNEL") == nullptr
+                                && !(pmcTune("PMC_VORO_PLAIN_PROP_ONLY") && (D.num_media > 1 || D.rf_store || D.explicit_absorption));
     const bool octree = D.grid_kind == PMC_GRID_OCTREE;
     if (pmcTune("PMC_NO_PEEL_SORT") == nullptr && (!octree || pmcPeelHasQueues((ctx->wide ? 1 : 0) | (D.num_media > 1 ? 2 : 0), ctx->walkLds)))
     {
@@ -577,7 +577,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                         int propBlocks = pmcVoroPropWavesPerSimd();
                         if (const char* v = pmcTune("PMC_VPROP_BLOCKS_PER_CU")) propBlocks = std::max(1, atoi(v));
                         HIP_TRY(pmcLaunchVoroProp(ctx->slot, tasks.propList, tasks.propCount, cursorSet(g, PMC_SORT_OBS), (xcdAffinity && pmcTune("PMC_VPROP_XCD_SEGMENTS")) ? 8 : 1, seed,
-                                                  ctx->numCU * propBlocks, sg));
+                                                  (D.rf_store ? 1 : 0) | (D.explicit_absorption ? 2 : 0) | (D.num_media > 1 ? 4 : 0), ctx->numCU * propBlocks, sg));
                         tasks.propCount = zeroCount;
                     }
                     else
@@ -601,7 +601,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
                     for (int k = 0; k < numSortObs; ++k)
                         if (voroPeelKernels && D.vobs_of_inst[sortObs[k]] >= 0)
                             HIP_TRY(pmcLaunchVoroPeel(ctx->slot, 1 + sortObs[k], D.vobs_of_inst[sortObs[k]], ctx->peelList[g][k], pmcPeelSortedCount(ctx->peelTemp[g][k]),
-                                                      cursorSet(g, 1 + k), xcdAffinity ? 8 : 1, ctx->numCU * peelBlocks, sp));
+                                                      cursorSet(g, 1 + k), xcdAffinity ? 8 : 1, D.num_media > 1 ? 1 : 0, ctx->numCU * peelBlocks, sp));
                     if (side)
                     {
                         HIP_TRY(hipEventRecord(ctx->evJoin[g], sp));

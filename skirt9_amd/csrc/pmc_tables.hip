@@ -485,7 +485,7 @@ int pmcUploadVoronoiGrid(pmc_ctx* ctx, const pmc_scene* scene, const pmc_medium&
             };
             // ---- all neighbours of a cell as a run (DevScene::vgen_run): what a PROPAGATION walk in voroPropKernel reads -- no mask, one run of
             // memory (4.75 lines per visit instead of header + mask + scattered entries: 6.2); left out where device memory is short
-            if (scene->num_media <= 1 && !pmcTune("PMC_VORO_NO_PROP_KERNEL"))
+            if (!pmcTune("PMC_VORO_NO_PROP_KERNEL"))
             {
                 size_t freeBytes = 0, totalBytes = 0;
                 const size_t need = 32 * size_t(g.vnbr_start[ncell]) + 96 * size_t(ncell);

@@ -266,6 +266,73 @@ def test_several_components_match_oracle(name, n, ea, tmp_path):
         assert (np.abs(gpu_rf - ref_rf) > 1e-6 * np.abs(ref_rf) + 1e-13 * ref_rf.max()).sum() == 0
 
 
+RF_ON = ('<RadiationFieldOptions storeRadiationField="true"><radiationFieldWLG type="DisjointWavelengthGrid"><LogWavelengthGrid minWavelength="0.15 micron" '
+         'maxWavelength="8 micron" numWavelengths="6"/></radiationFieldWLG></RadiationFieldOptions>')
+
+
+@pytest.mark.parametrize("rf,ea,mm", [(True, False, False), (False, True, False), (False, False, True), (True, True, False), (True, True, True)])
+def test_voronoi_flavours_run_in_the_voronoi_kernels(rf, ea, mm, tmp_path):
+    """Radiation field, explicit absorption and several medium components on a Voronoi grid (cfg5small with those options switched on): since
+    round 6 their propagation walks run in voroPropKernel<RF, EA, MM> and, with several components, their peel-off walks in voroPeelKernel<true>
+    (two lanes per walk on the tables of runs) instead of the generic one-lane-per-walk kernel (VoronoiMeshSnapshot.cpp:1058-1188 under
+    MediumSystem.cpp:849-932, 1075-1110, 1192-1260; MonteCarloSimulation.cpp:638-662).  The HIP engine against the oracle on the same histories --
+    frames, radiation field, counted work -- and against the generic kernel on the same tables (PMC_VORO_PLAIN_PROP_ONLY, PMC_VORO_NO_PEEL_KERNEL:
+    the same cells visited, frames to summation order)."""
+    import shutil
+    from skirt9_amd.engine import Engine, clear_tuning
+    name, n = "cfg5small.ski", 20000
+    text = open(ski(name)).read()
+    if mm:
+        assert text.count("</GeometricMedium>") == 1
+        text = text.replace("</GeometricMedium>", SECOND_COMPONENT)
+    if ea:
+        text = text.replace('explicitAbsorption="false"', 'explicitAbsorption="true"')
+    if rf:
+        assert '<RadiationFieldOptions storeRadiationField="false"/>' in text
+        text = text.replace('<RadiationFieldOptions storeRadiationField="false"/>', RF_ON)
+    for f in os.listdir(os.path.dirname(ski(name))):
+        if f.endswith(".txt"):
+            shutil.copy(ski(f), tmp_path / f)
+    path = tmp_path / "cfg5flavour.ski"
+    path.write_text(text)
+    sim = Simulation(str(path), num_packets=n).setup()
+    assert (sim.radiation_field_size > 0) == rf
+
+    def run(engine):
+        engine.run_primary(0, n, 90125)
+        c = engine.counters()
+        return engine.download(), (engine.download_radiation_field() if rf else None), c
+
+    eng = _engine(sim)
+    gpu, gpu_rf, c = run(eng)
+    if rf:
+        ref, ref_rf, counters = O.run_primary_rf(sim, 0, n, O.RNG_PHILOX, seed=90125)
+    else:
+        ref, counters = O.run_primary(sim, 0, n, O.RNG_PHILOX, seed=90125)
+    assert c["histories"] == n and c["stat_overflows"] == 0
+    assert abs(c["cell_visits"] - counters.cell_visits) <= 1e-4 * counters.cell_visits
+    assert abs(c["scatterings"] - counters.scatterings) <= 1e-4 * counters.scatterings + 2
+    _compare_frames(sim, gpu, ref, n)
+    if rf:
+        assert abs(gpu_rf.sum() - ref_rf.sum()) <= 1e-9 * ref_rf.sum()
+        assert np.array_equal(gpu_rf > 0, ref_rf > 0)
+        assert (np.abs(gpu_rf - ref_rf) > 1e-6 * np.abs(ref_rf) + 1e-13 * ref_rf.max()).sum() == 0
+    # the generic kernel on the same tables
+    set_tuning("PMC_VORO_PLAIN_PROP_ONLY", "1")
+    set_tuning("PMC_VORO_NO_PEEL_KERNEL", "1")
+    try:
+        other = Engine(sim.scene, 0)
+        frames, field, co = run(other)
+        other.close()
+    finally:
+        clear_tuning()
+    assert (co["histories"], co["cell_visits"], co["scatterings"], co["detector_updates"]) == \
+        (c["histories"], c["cell_visits"], c["scatterings"], c["detector_updates"])
+    assert np.allclose(frames, gpu, rtol=1e-10, atol=1e-13 * np.abs(gpu).max())
+    if rf:
+        assert np.allclose(field, gpu_rf, rtol=1e-9, atol=1e-13 * gpu_rf.max())
+
+
 def test_deep_octree_uses_the_wide_kernels():
     """cfg2deep.ski reaches level 12: the octree walk kernels with 21-bit index fields (and, for want of LDS next to the
     98 KB coordinate table, the peel-off kernel with service rounds and the propagation kernel without pass-1 records)"""
