@@ -23,22 +23,26 @@
 #define PMC_MAX_INSTRUMENTS 16  // (the observers with a peel-off packet of a cycle are flagged in sixteen bits of the slot's mode word;
                                 // the per-instrument slot arrays are sized by the scene's own instrument count)
 #define PMC_MAX_CONTEXTS 6  // scene slots in constant memory (live contexts per process and device; 6 x sizeof(DevScene) < 64 KB)
-#define PMC_MAX_LEVEL 15     // (box codes hold 20-bit byte offsets into the coordinate table: 24 x 2^15 bytes; size exponents 4 bits)
+#define PMC_MAX_LEVEL 20     // (box codes hold three 20-bit indices of the coordinate table and the size exponent; the packed indices of a walk 21 bits
+                             // per axis; link words and task records five bits of size exponent.  Rounds 1-5: 15.  TreePolicy allows maxLevel up to 99:
+                             // a tree of 2^20 finest cells per axis resolves 0.04 pc in a box of 40 kpc)
 #define PMC_STAT_CAP 48     // entries of a slot's own contribution list per instrument: DISTINCT pixels a history contributes to
                             // (FluxRecorder statistics); a multiple of 4.  A history with more distinct pixels continues its list in
                             // chained blocks of PMC_STAT_CAP entries from the slot group's pool (DevScene::stat_pool_*): the
                             // reference's list is unbounded (FluxRecorder.hpp:327-338)
 #define PMC_STAT_POOL_EXHAUSTED 0x40000000  // flag in the length word of a list head: a contribution was lost because the pool had no block left
 
-// link word (uint32): bits 0-3 size exponent e of the target box (its edge spans 2^e finest cells), bits 4-29 index,
+// link word (uint32): bits 0-4 size exponent e of the target box (its edge spans 2^e finest cells), bits 5-29 index,
 // bits 30-31 kind: 0 leaf cell (device index), PMC_LINK_NODE internal node (NodeRec index), PMC_LINK_OCTET internal node
 // whose eight children are all leaves (index = device index of child 0; the children are consecutive cells in child order,
 // e = exponent of the NODE); PMC_LINK_NONE: outside the grid (test it first: its bit 30 is set)
 #define PMC_LINK_NONE 0x7FFFFFFFu
 #define PMC_LINK_NODE 0x80000000u
 #define PMC_LINK_OCTET 0x40000000u
-#define PMC_LINK_INDEX_MASK 0x3FFFFFFu
-#define PMC_LINK_MAX_INDEX ((1u << 26) - 2u)
+#define PMC_LINK_EXP_BITS 5
+#define PMC_LINK_EXP_MASK 31u
+#define PMC_LINK_INDEX_MASK 0x1FFFFFFu
+#define PMC_LINK_MAX_INDEX ((1u << 25) - 2u)
 
 // Octree cells.  A walk step leaves its cell through ONE wall and needs the cell's density and the link through that
 // wall: the step gathers the cell's HOT record CellRec (32 bytes: two 16-byte loads from one sector, issued as soon as the
@@ -58,9 +62,10 @@ static_assert(sizeof(CellRec) == 32, "CellRec must be 32 bytes");
 
 struct LeafRec
 {
-    uint64_t code;      // box code: bits 0-19 / 20-39 / 40-59 = byte offsets of the lower x / y / z wall coordinate in the LDS
-                        // table [3][2^Lmax+1] (8*fx, 8*(tabn+fy), 8*(2 tabn+fz) with fine lower-corner indices f), bits
-                        // 60-63 = size exponent e = Lmax - level (the box spans 2^e finest cells per axis)
+    uint64_t code;      // box code: bits 0-19 / 20-39 / 40-59 = fine lower-corner indices fx / fy / fz: the entries of the lower walls in
+                        // the coordinate table [3][2^Lmax+1] of their axis; bits 60-63 = size exponent e = Lmax - level (the box spans
+                        // 2^e finest cells per axis), or 15 for e >= 15 with e - 15 in the low five bits of fx (zero in such a box);
+                        // pmc_walk.inc decodeBoxWords
     double   density;   // number density n[m]
 };
 static_assert(sizeof(LeafRec) == 16, "LeafRec must be 16 bytes");
@@ -169,7 +174,8 @@ struct TaskArrays
                                             // derives the index of the history each of those slots takes up next
 };
 #define PMC_TASK_NONE 0xFFFFFFFFu
-#define PMC_TASK_MOVED 0x1000u  // octree: bit 12 of TaskArrays::bits: PathSegmentGenerator::moveInside has moved the start of the walk (the
+#define PMC_TASK_EXP_MASK 31u   // octree: bits 8-12 of TaskArrays::bits: size exponent of the first cell
+#define PMC_TASK_MOVED 0x2000u  // octree: bit 13 of TaskArrays::bits: PathSegmentGenerator::moveInside has moved the start of the walk (the
                                 // position was outside the grid): position and initial path length are in the record; otherwise the
                                 // walk starts at the slot's position (SlotArrays::rx ...) with no initial length, and the record holds
                                 // neither (nor, ever, the direction of a propagation walk: it is the slot's)

@@ -148,19 +148,21 @@ namespace
             T.cellExt.assign(T.cellSlots, -1);
             for (int m = 0; m < n; ++m) T.cellExt[T.perm[m]] = m;
         }
-        // box code (pmc_device.h LeafRec::code): LDS byte offsets of the three lower wall entries + size exponent
+        // box code (pmc_walk.inc decodeBoxWords): the indices of the three lower walls in the coordinate table of their axis + size exponent
+        // (e >= 15: the field holds 15 and the low bits of the x index, zero in such a box, hold e - 15)
         auto code = [&](int id) -> uint64_t {
-            const uint64_t ox = 8ull * uint64_t(fx[id]);
-            const uint64_t oy = 8ull * uint64_t(T.tabn + fy[id]);
-            const uint64_t oz = 8ull * uint64_t(2 * T.tabn + fz[id]);
-            return ox | (oy << 20) | (oz << 40) | ((uint64_t)(maxLevel - g.node_level[id]) << 60);
+            const uint64_t e = uint64_t(maxLevel - g.node_level[id]);
+            uint64_t ix = uint64_t(fx[id]);
+            const uint64_t iy = uint64_t(fy[id]), iz = uint64_t(fz[id]);
+            if (e >= 15) ix |= e - 15;
+            return ix | (iy << 20) | (iz << 40) | (std::min<uint64_t>(e, 15) << 60);
         };
-        // link word (pmc_device.h): size exponent | index << 4 | node flag
+        // link word (pmc_device.h): size exponent | index << PMC_LINK_EXP_BITS | node flag
         auto linkOf = [&](int id) -> uint32_t {
             if (id < 0) return PMC_LINK_NONE;
             const uint32_t e = uint32_t(maxLevel - g.node_level[id]);
-            return g.node_first_child[id] < 0 ? (e | (uint32_t(T.perm[g.node_cell[id]]) << 4))
-                                              : (e | (uint32_t(internalIndex[id]) << 4) | PMC_LINK_NODE);
+            return g.node_first_child[id] < 0 ? (e | (uint32_t(T.perm[g.node_cell[id]]) << PMC_LINK_EXP_BITS))
+                                              : (e | (uint32_t(internalIndex[id]) << PMC_LINK_EXP_BITS) | PMC_LINK_NODE);
         };
         // the link of a cell record through a wall: as linkOf, but an internal node whose children are all leaves with
         // consecutive device indices in child order becomes an octet link (the walk picks the child without a load)
@@ -172,7 +174,7 @@ namespace
             const int base = T.perm[g.node_cell[first]];
             for (int l = 1; l < 8; ++l)
                 if (T.perm[g.node_cell[first + l]] != base + l) return linkOf(id);
-            return uint32_t(maxLevel - g.node_level[id]) | (uint32_t(base) << 4) | PMC_LINK_OCTET;
+            return uint32_t(maxLevel - g.node_level[id]) | (uint32_t(base) << PMC_LINK_EXP_BITS) | PMC_LINK_OCTET;
         };
         T.rootLink = linkOf(0);
         // top-down search table (pmc_walk.inc topDown): per cell of the regular grid of level Lc the node of level Lc
@@ -285,7 +287,7 @@ int pmcUploadOctreeGrid(pmc_ctx* ctx, const pmc_scene* scene, const pmc_medium& 
         D.lmax = T.lmax;
         D.root_link = T.rootLink;
         if (size_t(T.cellSlots) > PMC_LINK_MAX_INDEX || T.internals.size() > PMC_LINK_MAX_INDEX)
-            return (fail(PMC_ERR_UNSUPPORTED, "octree with 2^26 cells or nodes or more (26-bit link index)"));
+            return (fail(PMC_ERR_UNSUPPORTED, "octree with 2^25 cells or nodes or more (25-bit link index)"));
         D.tab_stride_bytes = 8u * uint32_t(T.tabn);
         D.fine_scale[0] = double(1 << T.lmax) / (g.xmax - g.xmin);
         D.fine_scale[1] = double(1 << T.lmax) / (g.ymax - g.ymin);
@@ -301,7 +303,7 @@ int pmcUploadOctreeGrid(pmc_ctx* ctx, const pmc_scene* scene, const pmc_medium& 
         if ((rc = ctx->upload(T.cellExt.data(), T.cellExt.size(), &D.cell_ext))) return rc;
         devToCell = T.cellExt;
         D.cell_slots = T.cellSlots;
-        // (levels 13-15: 0.2-0.8 MB: not in LDS; the walk reads the six walls of a step from global memory)
+        // (levels 13-20: 0.2 ... 25 MB: not in LDS; the walk reads the six walls of a step from global memory)
         D.tab_in_lds = T.lmax <= 12 ? 1 : 0;
         D.lds_grid_len = D.tab_in_lds ? 3 * T.tabn : 0;
     return rc;

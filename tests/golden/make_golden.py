@@ -45,6 +45,8 @@ Fixtures:
                thread; the two SED files as written, and every FITS frame (flux components, statistics w^0 .. w^4) summed over
                8 x 8 blocks of the 512^2 pixels in double precision (the ten 1 MB FITS files themselves are not committed)
   cfg5dd_cells.npz   the same grid with its sites drawn from the dust density (policy DustDensity): volumes, densities
+  cfg4deepest_*   an 18-level octree around a cusp of nested smoothed particles (tests/ski/cfg4deepest.ski): 88 rays, half of them through the
+                  deepest levels, and the cell table
   cfg5peak_*, cfg5imp_*   Voronoi site policies CentralPeak and ImportedSites (tests/ski/cfg5peak.ski, cfg5imp.ski): 40 rays and the cell table
   cfg4small_*  reduced config 4 (tests/ski/cfg4small.ski): dust imported from 3000 smoothed particles
                (tests/ski/cfg4small_sph.txt, made by tools/make_sph.py), 2x10^4 packets -> files, rays, cells
@@ -78,6 +80,18 @@ def rays(scale, n, seed):
             (np.zeros(3), np.array([s2, s2, 0])), (np.array([scale * 0.25, scale * 0.125, 0.0]), np.array([0, 0, -1.0])),
             (np.array([-scale * 2, 0.0, 0.0]), np.array([1.0, 0, 0])), (np.array([-scale * 2, 1.0, 1.0]), np.array([-1.0, 0, 0])),
             (np.array([1e15, 2e15, -3e15]), np.array([0.3, 0.5, 0.81]) / np.linalg.norm([0.3, 0.5, 0.81]))]
+    return out
+
+
+def rays_towards(centre, scale, n, seed):
+    """rays that pass a point at impact parameters from `scale` down to scale / 2^(n/2): through the deepest levels of a tree refined around it"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        k = rng.normal(size=3)
+        k /= np.linalg.norm(k)
+        b = (rng.random(3) - 0.5) * 2 * scale * 2.0 ** (-0.5 * i)
+        out.append((np.array(centre) + b - k * 30 * scale, k))
     return out
 
 
@@ -143,7 +157,7 @@ def main():
         sys.exit("build the reference first: make -f oracle/Makefile.ref -j8")
     for name, scale in (("cfg1", 3.08567758e16), ("cfg1mesh", 3.08567758e16), ("cfg1mesh2", 3.08567758e16), ("cfg2small", 4000 * 3.08567758e16), ("cfg2deep", 300 * 3.08567758e16), ("cfg2deeper", 100 * 3.08567758e16), ("cfg3small", None), ("cfg3z", None), ("cfg1nf", None), ("cfg2nf", None),
                         ("cfg4small", 4000 * 3.08567758e16), ("cfg1file", None), ("cfg1sed", None), ("cfg3sed", None), ("cfg3norm", "sed"), ("cfg3disk", "sed"), ("cfg3multi", "sed"), ("cfg3ten", "sed"), ("cfg3flat", "sed"), ("cfg3off", "sed"), ("cfg3plum", "sed"), ("cfg1rf", "rf"), ("cfg3rf", "rf"), ("cfg2ea", None), ("cfg1nfea", None), ("cfg1rfea", "rf"), ("cfg2mm", None), ("cfg2mmea", None), ("cfg1mmnf", None), ("cfg3mm", None), ("cfg1mmrf", "rf"), ("cfg1con", None), ("cfg1netzer", None), ("cfg1laser", None), ("cfg2agn", None), ("cfg1nomed", None),
-                        ("cfg5small", 4000 * 3.08567758e16), ("cfg5dd", "cells"), ("cfg5peak", "cellrays"), ("cfg5imp", "cellrays"), ("cfg2shell", "cells"), ("cfg2torus", "cells"), ("cfg2ring", "cells"), ("cfg1list", "cells")):
+                        ("cfg5small", 4000 * 3.08567758e16), ("cfg5dd", "cells"), ("cfg5peak", "cellrays"), ("cfg5imp", "cellrays"), ("cfg4deepest", "cellrays"), ("cfg2shell", "cells"), ("cfg2torus", "cells"), ("cfg2ring", "cells"), ("cfg1list", "cells")):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         ski = os.path.join(ROOT, "tests", "ski", name + ".ski")
@@ -192,7 +206,11 @@ def main():
             # rays: directions are written as hex floats so that both sides parse identical doubles
             rayfile = os.path.join(HERE, name + "_rays.txt")
             with open(rayfile, "w") as fh:
-                for r, k in rays(scale, 40, 1):
+                some = rays(scale, 40, 1)
+                if name == "cfg4deepest":
+                    # (an 18-level octree around one point: rays that pass it at 100 pc ... 1e-4 pc)
+                    some += rays_towards([1234.5 * 3.08567758e16, -567.25 * 3.08567758e16, 89.125 * 3.08567758e16], 100 * 3.08567758e16, 40, 3)
+                for r, k in some:
                     fh.write(" ".join(float(v).hex() for v in list(r) + list(k)) + "\n")
             subprocess.check_call([REF, "rays", ski, rayfile, os.path.join(HERE, name + "_rays_ref.txt"), "-o", tmp], cwd=tmp,
                                   stdout=subprocess.DEVNULL)

@@ -55,6 +55,34 @@ def test_trace_ray_bit_exact(name, scale):
         assert np.array_equal(ds_ref.view(np.uint64), ds_gpu.view(np.uint64)), (r, k)
 
 
+def test_deepest_octree_rays_equal_the_reference():
+    """tests/ski/cfg4deepest.ski: an octree of EIGHTEEN levels (TreePolicy.hpp:32-35 allows maxLevel up to 99; rounds 1-5 stopped at 15: 20-bit
+    byte offsets in the box codes, 4-bit size exponents in links and task records).  The traversal kernel against the REFERENCE's own (m, ds)
+    dump (tests/golden/cfg4deepest_rays_ref.txt: 88 rays, half of them aimed at the cusp the tree is refined around, up to 100 segments each),
+    bit for bit (TreeSpatialGrid.cpp:140-216)."""
+    from conftest import golden
+    sim = Simulation(ski("cfg4deepest.ski")).setup()
+    eng = _engine(sim)
+    rays = [[float.fromhex(t) for t in line.split()] for line in open(golden("cfg4deepest_rays.txt"))]
+    ref = open(golden("cfg4deepest_rays_ref.txt")).read().split("\n")
+    pos = total = deep = 0
+    for i, ray in enumerate(rays):
+        head = ref[pos].split()
+        assert head[0] == "ray" and int(head[1]) == i
+        n = int(head[2])
+        k = np.array([float.fromhex(v) for v in head[3:6]])  # the direction as normalised by the reference
+        m_ref = np.array([int(ref[pos + 1 + j].split()[0]) for j in range(n)], dtype=np.int32)
+        ds_ref = np.array([float.fromhex(ref[pos + 1 + j].split()[1]) for j in range(n)])
+        pos += 1 + n
+        m, ds = eng.trace_ray(np.array(ray[:3]), k)
+        assert len(m) == n, (i, len(m), n)
+        assert np.array_equal(m, m_ref), i
+        assert np.array_equal(ds.view(np.uint64), ds_ref.view(np.uint64)), i
+        total += n
+        deep += int((ds_ref[ds_ref > 0] < 0.5 * 3.0857e16).sum())   # segments shorter than half a parsec: cells of level >= 17
+    assert total > 3000 and deep > 200
+
+
 def _pixel_shapes(sim):
     """(ny, nx) of every instrument of the ski file in order ((1, 1) for an SEDInstrument: FluxRecorder's one bin)"""
     import re
@@ -144,7 +172,7 @@ def _compare_frames(sim, gpu, ref, n):
             assert a[:lay.num_lambda].sum() == n
 
 
-@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg2nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg1file.ski", 20000), ("cfg3file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg3ten.ski", 20000), ("cfg3twelve.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg1long.ski", 5000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000), ("cfg2deep.ski", 20000), ("cfg2deeper.ski", 20000), ("cfg2ea.ski", 20000), ("cfg1nfea.ski", 50000), ("cfg2mm.ski", 20000), ("cfg2mmea.ski", 20000), ("cfg1mmnf.ski", 50000), ("cfg3mm.ski", 20000), ("cfg1con.ski", 20000), ("cfg1netzer.ski", 20000), ("cfg1laser.ski", 20000), ("cfg2agn.ski", 20000), ("cfg1nomed.ski", 20000)])
+@pytest.mark.parametrize("name,n", [("cfg1.ski", 20000), ("cfg2small.ski", 20000), ("cfg3small.ski", 20000), ("cfg1nf.ski", 50000), ("cfg2nf.ski", 50000), ("cfg4small.ski", 20000), ("cfg4deepest.ski", 20000), ("cfg1file.ski", 20000), ("cfg3file.ski", 20000), ("cfg5small.ski", 20000), ("cfg1sed.ski", 20000), ("cfg3sed.ski", 20000), ("cfg3disk.ski", 20000), ("cfg3plum.ski", 20000), ("cfg3multi.ski", 20000), ("cfg3ten.ski", 20000), ("cfg3twelve.ski", 20000), ("cfg1mesh.ski", 20000), ("cfg1mesh2.ski", 20000), ("cfg1long.ski", 5000), ("cfg3flat.ski", 20000), ("cfg3off.ski", 20000), ("cfg3z.ski", 20000), ("cfg2deep.ski", 20000), ("cfg2deeper.ski", 20000), ("cfg2ea.ski", 20000), ("cfg1nfea.ski", 50000), ("cfg2mm.ski", 20000), ("cfg2mmea.ski", 20000), ("cfg1mmnf.ski", 50000), ("cfg3mm.ski", 20000), ("cfg1con.ski", 20000), ("cfg1netzer.ski", 20000), ("cfg1laser.ski", 20000), ("cfg2agn.ski", 20000), ("cfg1nomed.ski", 20000)])
 def test_photon_loop_matches_oracle(name, n):
     sim = Simulation(ski(name), num_packets=n).setup()
     eng = _engine(sim)
@@ -342,10 +370,14 @@ def test_deep_octree_uses_the_wide_kernels():
     levels = np.ctypeslib.as_array(g.node_level, (g.num_nodes,))
     assert levels.max() == 12
     # cfg2deeper.ski reaches level 14: the coordinate table (3 x 16385 doubles) does not fit in LDS, the walk kernels read the walls
-    # of a step from global memory (TreePolicy allows maxLevel up to 99; the engine's box codes hold levels up to 15)
+    # of a step from global memory (TreePolicy allows maxLevel up to 99; the engine's box codes hold levels up to 20)
     sim = Simulation(ski("cfg2deeper.ski")).setup()
     g = scene_head(sim).grid
     assert np.ctypeslib.as_array(g.node_level, (g.num_nodes,)).max() == 14
+    # cfg4deepest.ski reaches level 18 (round 6: box codes of three table indices, five-bit size exponents; PMC_MAX_LEVEL = 20)
+    sim = Simulation(ski("cfg4deepest.ski")).setup()
+    g = scene_head(sim).grid
+    assert np.ctypeslib.as_array(g.node_level, (g.num_nodes,)).max() == 18
 
 
 def test_eight_observers_and_three_slot_groups():

@@ -41,7 +41,7 @@ def test_byte_identical_to_reference(name, nfiles, tmp_path):
         assert _same_file(golden(f), str(tmp_path / f)), f"{f} differs from the reference output"
 
 
-@pytest.mark.parametrize("name", ["cfg1", "cfg1mesh", "cfg1mesh2", "cfg2small", "cfg2deep", "cfg2deeper", "cfg4small", "cfg5small", "cfg5peak", "cfg5imp"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg1mesh", "cfg1mesh2", "cfg2small", "cfg2deep", "cfg2deeper", "cfg4small", "cfg4deepest", "cfg5small", "cfg5peak", "cfg5imp"])
 def test_ray_segments_bit_exact(name):
     """PathSegmentGenerator (m, ds) sequences dumped from the reference (skirt_ref rays) vs the oracle's generators"""
     sim = Simulation(ski(name + ".ski")).setup()
