@@ -178,7 +178,7 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         ctx->numGroups = std::min(PMC_MAX_GROUPS, std::max(1, atoi(env)));
         ctx->groupsConfigured = true;  // (an explicit setting: also a Voronoi scene runs with it)
     }
-    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), 16 * sizeof(unsigned long long)) != hipSuccess)
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), 24 * sizeof(unsigned long long)) != hipSuccess)
         return bail(fail(PMC_ERR_DEVICE, "hipHostMalloc failed"));
 
     DevScene& D = ctx->dev;

@@ -130,6 +130,7 @@ struct pmc_ctx
     unsigned long long overflowsSeen{0};  // statistics-list overflows already reported (pmc_run_primary)
     int32_t* statPoolIota{nullptr};       // 0, 1, 2, ...: the free list of a statistics pool none of whose blocks is in use
     int64_t statPoolBlocks{0};
+    int statPoolGrowths{0};               // times the pool has grown (pmc_run_primary)
     // radiation field on an octree: per slot group the log of a generation's contributions (two buffers each for the
     // partitioning sort) and the sort's temporary storage
     std::vector<void*> rfAllocations;

@@ -498,11 +498,89 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     if (const char* env = pmcTune("PMC_CYCLE_BLOCKS_PER_CU")) cycleBlocks = ctx->numCU * std::max(1, atoi(env));
     int transitionBlocks = ctx->numCU * 4;  // persistent transition workgroups (tables staged once per workgroup)
     if (const char* env = pmcTune("PMC_TRANSITION_BLOCKS_PER_CU")) transitionBlocks = ctx->numCU * std::max(1, atoi(env));
+    // ---- statistics: the pool of list blocks GROWS when a slot group could run out of blocks in its next generation (round 6; rounds 1-5
+    // failed the segment with PMC_ERR_OVERFLOW: the reference's list is a std::vector, FluxRecorder.hpp:327-338).  A history takes at most one
+    // block per instrument and generation, so a group whose free blocks number at least its live slots x instruments with statistics cannot
+    // run out; when they do not, everything in flight is waited for, the pool arrays are allocated anew with room for `add` more blocks (the
+    // old contents copied, as a std::vector grows), the new blocks go to the free stack of the group that asked, and the scene constants are
+    // uploaded again.  No device memory for it: the segment goes on with the pool it has (and fails loudly if that does run out).
+    int statInstruments = 0;
+    for (int i = 0; i < D.num_instruments; ++i) statInstruments += D.inst[i].record_stats ? 1 : 0;
+    const bool poolGrows = D.any_stats && ctx->statPoolBlocks > 0 && pmcTune("PMC_STAT_POOL_NO_GROWTH") == nullptr;
+    auto growStatPool = [&](int g, int64_t need) -> int {
+        HIP_TRY(hipDeviceSynchronize());
+        unsigned long long freeNow[PMC_MAX_GROUPS] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(freeNow, ctr + PMC_CTR_STATFREE(0), sizeof(freeNow), hipMemcpyDeviceToHost));
+        const int64_t old = ctx->statPoolBlocks;
+        const int64_t add = std::min<int64_t>(std::max<int64_t>(2 * need, old), (int64_t(1) << 30) - old);
+        if (add <= 0) return PMC_OK;
+        size_t freeBytes = 0, totalBytes = 0;
+        const size_t bytes = size_t(old + add) * (PMC_STAT_CAP * 12 + 12);
+        if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && bytes + (size_t(1) << 30) > freeBytes)
+        {
+            static std::atomic<bool> said{false};
+            if (!said.exchange(true))
+                fprintf(stderr, "libpmc: the statistics lists of the histories in flight need more blocks than the pool of %lld has, and device %d has no room for "
+                                "%.1f GB more: the segment goes on and fails if the pool does run out (PMC_NUM_SLOTS lowers the number of histories in flight)\n",
+                        (long long)old, ctx->device, bytes * 1e-9);
+            return PMC_OK;
+        }
+        int32_t *bin = nullptr, *next = nullptr, *stack = nullptr, *iota = nullptr;
+        double* w = nullptr;
+        auto& own = ctx->slotAllocations;
+        int rc;
+        if ((rc = ctx->allocate<int32_t>(size_t(old + add) * PMC_STAT_CAP, &bin, false, &own))) return rc;
+        if ((rc = ctx->allocate<double>(size_t(old + add) * PMC_STAT_CAP, &w, false, &own))) return rc;
+        if ((rc = ctx->allocate<int32_t>(size_t(old + add), &next, false, &own))) return rc;
+        if ((rc = ctx->allocate<int32_t>(size_t(old + add), &stack, false, &own))) return rc;
+        if ((rc = ctx->allocate<int32_t>(size_t(old + add), &iota, false, &own))) return rc;
+        HIP_TRY(hipMemcpy(bin, D.stat_pool_bin, size_t(old) * PMC_STAT_CAP * sizeof(int32_t), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(w, D.stat_pool_w, size_t(old) * PMC_STAT_CAP * sizeof(double), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(next, D.stat_pool_next, size_t(old) * sizeof(int32_t), hipMemcpyDeviceToDevice));
+        std::vector<int32_t> ids(static_cast<size_t>(old + add));
+        for (size_t i = 0; i < ids.size(); ++i) ids[i] = (int32_t)i;
+        HIP_TRY(hipMemcpy(iota, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        // the free stacks: every group keeps its stack (its first freeNow entries), the new ids go on top of group g's
+        int32_t first = 0;
+        for (int h = 0; h < PMC_MAX_GROUPS; ++h)
+        {
+            const int32_t count = D.stat_pool_count[h] + (h == g ? int32_t(add) : 0);
+            if (D.stat_pool_count[h] > 0 && freeNow[h] > 0)
+                HIP_TRY(hipMemcpy(stack + first, D.stat_pool_free + D.stat_pool_first[h], size_t(freeNow[h]) * sizeof(int32_t), hipMemcpyDeviceToDevice));
+            if (h == g) HIP_TRY(hipMemcpy(stack + first + freeNow[h], ids.data() + old, size_t(add) * sizeof(int32_t), hipMemcpyHostToDevice));
+            D.stat_pool_first[h] = first;
+            D.stat_pool_count[h] = count;
+            first += count;
+        }
+        freeNow[g] += (unsigned long long)add;
+        HIP_TRY(hipMemcpy(ctr + PMC_CTR_STATFREE(0), freeNow, sizeof(freeNow), hipMemcpyHostToDevice));
+        // the old arrays
+        for (void* gone : {(void*)D.stat_pool_bin, (void*)D.stat_pool_w, (void*)D.stat_pool_next, (void*)D.stat_pool_free, (void*)ctx->statPoolIota})
+        {
+            own.erase(std::remove(own.begin(), own.end(), gone), own.end());
+            hipFree(gone);
+        }
+        D.stat_pool_bin = bin, D.stat_pool_w = w, D.stat_pool_next = next, D.stat_pool_free = stack;
+        ctx->statPoolIota = iota;
+        ctx->statPoolBlocks = old + add;
+        ctx->pinned[4 * PMC_MAX_GROUPS + g] = freeNow[g];
+        ctx->statPoolGrowths += 1;
+        HIP_TRY(pmcUploadScene(ctx->slot, &D, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return PMC_OK;
+    };
     auto enqueue = [&](int g, bool initial) -> int {
         hipStream_t sg = ctx->groupStream[g];
         // the list of live slots the previous generation left (as many as its live count, which came back with the stream)
         int* const listIn = (!initial && listBuilt[g]) ? D.tasks.liveList + int64_t(listHalf[g]) * D.slots.num_slots + base[g] : nullptr;
         const int listLen = listIn ? int(ctx->pinned[g]) : 0;
+        if (!initial && poolGrows)
+        {
+            // (the group's free blocks came back with its live count: enough for one block per live slot and instrument with statistics?)
+            const int64_t need = int64_t(ctx->pinned[g]) * statInstruments;
+            if (int64_t(ctx->pinned[4 * PMC_MAX_GROUPS + g]) < need)
+                if (int rc = growStatPool(g, need)) return rc;
+        }
         if (!initial)
         {
             // (the radiation-field log of the group's previous generation: its size came back with the live count)
@@ -658,6 +736,8 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
             HIP_TRY(hipMemcpyAsync(ctx->pinned + 3 * PMC_MAX_GROUPS + g, ctr + PMC_CTR_HISTORY, sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
         if (statLogged && !initial && ctx->statCap[g])
             HIP_TRY(hipMemcpyAsync(ctx->pinned + 2 * PMC_MAX_GROUPS + g, ctr + PMC_CTR_STATLOG(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
+        if (poolGrows)
+            HIP_TRY(hipMemcpyAsync(ctx->pinned + 4 * PMC_MAX_GROUPS + g, ctr + PMC_CTR_STATFREE(g), sizeof(unsigned long long), hipMemcpyDeviceToHost, sg));
         return PMC_OK;
     };
     // on any failure: no kernel of this segment may still be running (or be timed) when the call returns

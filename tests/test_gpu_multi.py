@@ -83,22 +83,27 @@ def _many_events(tmp_path, events):
     return str(path)
 
 
-def test_statistics_lists_are_unbounded(tmp_path):
+@pytest.mark.parametrize("events,n,pool", [(120, 2000, None), (400, 600, None), (120, 2000, "16")])
+def test_statistics_lists_are_unbounded(tmp_path, monkeypatch, events, n, pool):
     """FluxRecorder::recordContributions (FluxRecorder.cpp:962-1014, FluxRecorder.hpp:327-338) keeps any number of
     contributions per history.  A slot's own list holds 48 distinct pixels per instrument; a history with more continues
-    in chained blocks from the slot group's pool.  120 scattering events per history (every history leaves its own list):
-    the statistics arrays must agree with the oracle's, which keeps a std::vector per history."""
+    in chained blocks from the slot group's pool.  120 / 400 scattering events per history (every history leaves its own list):
+    the statistics arrays must agree with the oracle's, which keeps a std::vector per history.  With a pool of 16 blocks
+    (PMC_STAT_POOL_BLOCKS) the same segment must complete as well: the pool grows between the generations of a slot group
+    (round 6; rounds 1-5 failed such a segment with PMC_ERR_OVERFLOW)."""
     import oracle_lib as O
     from skirt9_amd.engine import Engine
     from skirt9_amd.host import Simulation
     from test_gpu_parity import _compare_frames
-    n = 2000
-    sim = Simulation(_many_events(tmp_path, 120), num_packets=n).setup()
+    if pool:
+        monkeypatch.setenv("PMC_STAT_POOL_BLOCKS", pool)
+    sim = Simulation(_many_events(tmp_path, events), num_packets=n).setup()
     eng = Engine(sim.scene, 0)
     eng.run_primary(0, n, 1)
     gpu = eng.download()
     c = eng.counters()
     eng.close()
+    # (a packet's weight underflows to zero after some 120 forced scatterings in this scene, which ends the history whatever minScattEvents asks)
     assert c["stat_overflows"] == 0 and c["scatterings"] >= 100 * n
     ref, counters = O.run_primary(sim, 0, n, O.RNG_PHILOX, seed=1)
     _compare_frames(sim, gpu, ref, n)
@@ -109,22 +114,26 @@ def test_statistics_lists_are_unbounded(tmp_path):
         b = ref[lay.wifu_offset + k * npix:lay.wifu_offset + (k + 1) * npix]
         assert abs(a.sum() - b.sum()) <= 1e-9 * np.abs(b).sum()
     # sum of w^0 over the pixels = number of (history, distinct pixel) pairs: beyond 48 per history on average
-    assert ref[lay.wifu_offset:lay.wifu_offset + npix].sum() > 50 * n
+    assert ref[lay.wifu_offset:lay.wifu_offset + npix].sum() > 50 * n   # (beyond the 48 entries of a slot's own list)
     assert gpu[lay.wifu_offset:lay.wifu_offset + npix].sum() == ref[lay.wifu_offset:lay.wifu_offset + npix].sum()
 
 
 def test_statistics_pool_exhaustion_is_an_error(tmp_path, monkeypatch):
     """the pool of list blocks is finite (device memory): a segment that runs out of blocks must FAIL instead of returning
     statistics computed from truncated lists; the next segment starts with a full pool again"""
-    from skirt9_amd.engine import Engine
+    from skirt9_amd.engine import Engine, set_tuning, clear_tuning
     from skirt9_amd.host import Simulation
     monkeypatch.setenv("PMC_STAT_POOL_BLOCKS", "16")
-    sim = Simulation(_many_events(tmp_path, 120), num_packets=500).setup()
-    eng = Engine(sim.scene, 0)
-    with pytest.raises(RuntimeError, match="PMC_STAT_POOL_BLOCKS"):
-        eng.run_primary(0, 500, 1)
-    assert eng.counters()["stat_overflows"] > 0
-    eng.close()
+    set_tuning("PMC_STAT_POOL_NO_GROWTH", "1")   # (the pool as rounds 1-5 had it: what happens when the device has no memory left for more blocks)
+    try:
+        sim = Simulation(_many_events(tmp_path, 120), num_packets=500).setup()
+        eng = Engine(sim.scene, 0)
+        with pytest.raises(RuntimeError, match="PMC_STAT_POOL_BLOCKS"):
+            eng.run_primary(0, 500, 1)
+        assert eng.counters()["stat_overflows"] > 0
+        eng.close()
+    finally:
+        clear_tuning()
     sim = Simulation(_many_events(tmp_path, 20), num_packets=500).setup()
     eng = Engine(sim.scene, 0)
     eng.run_primary(0, 500, 1)
