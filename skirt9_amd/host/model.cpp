@@ -907,7 +907,7 @@ namespace skh
                                        "Voronoi sites");
             for (const Array& row : rows) sites.push_back(Vec3{row[0], row[1], row[2]});
         }
-        mesh.build(extent, std::move(sites));
+        mesh.build(extent, std::move(sites), relaxSites);
     }
 
     Vec3 VoronoiSpatialGrid::randomPositionInCell(int m, Random& random) const

@@ -526,6 +526,7 @@ namespace skh
     public:
         std::string policy{"Uniform"};
         int numSites{500};
+        bool relaxSites{false};  // VoronoiMeshSpatialGrid::relaxSites: one relaxation step of the sites before the final tessellation
         std::string sitesPath;  // resolved file path (policy File)
         VoronoiMesh mesh;
 

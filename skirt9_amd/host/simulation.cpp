@@ -623,7 +623,7 @@ namespace skh
                 if (filename.empty()) throw std::runtime_error("ski: VoronoiMeshSpatialGrid lacks a filename");
                 grid->sitesPath = (filename[0] == '/') ? filename : _inputPath + "/" + filename;
             }
-            if (rd.boolean(*ge, "relaxSites", false)) unsupported("relaxSites");
+            grid->relaxSites = rd.boolean(*ge, "relaxSites", false);
             _grid = std::move(grid);
         }
         else

@@ -135,7 +135,7 @@ namespace skh
         };
     }
 
-    void VoronoiMesh::build(const Box& extent, std::vector<Vec3> sites)
+    void VoronoiMesh::build(const Box& extent, std::vector<Vec3> sites, bool relax)
     {
         _extent = extent;
         _eps = 1e-12 * extent.diagonal();  // VoronoiMeshSnapshot::setExtent (:393-397)
@@ -160,6 +160,18 @@ namespace skh
         _sites = sites;
         const int N = numCells();
         if (N <= 0) throw std::runtime_error("Voronoi grid without sites inside the domain");
+        // ---- VoronoiMeshSnapshot::buildMesh with relaxSites (:550-601): ONE relaxation step -- every site moves to the centroid of its cell in
+        // the tessellation of the sites as given (order, and thus the cell indices, stay as they are); the final tessellation follows below.
+        // (The reference takes the centroid from Voro++, voronoicell_base::centroid; this one sums the same tetrahedra over the faces of its own
+        // polyhedron: the relaxed sites agree with the reference's to rounding, not bit for bit.)
+        if (relax)
+        {
+            std::vector<Vec3> moved(_sites);
+            build(extent, std::move(sites), false);  // (the tessellation of the sites as given; fills _centroids)
+            for (int m = 0; m != N; ++m) moved[m] = Vec3{moved[m].x + _centroids[m].x, moved[m].y + _centroids[m].y, moved[m].z + _centroids[m].z};
+            _sites = moved;
+        }
+        _centroids.assign(N, Vec3{0., 0., 0.});
 
         // ---- bucket grid over the sites for the neighbour candidates
         const int nbk = std::max(1, static_cast<int>(std::cbrt(N / 2.0)));
@@ -219,9 +231,10 @@ namespace skh
                         if (P.clip(nu, dot(nu, mid), cand.second, tol)) rmax2 = P.maxRadius2(pr);
                     }
                 }
-                // neighbours, bounding box, volume
+                // neighbours, bounding box, volume, centroid (relative to the site: the sum over the tetrahedra site - face fan)
                 Box bb(DBL_MAX, DBL_MAX, DBL_MAX, -DBL_MAX, -DBL_MAX, -DBL_MAX);
                 double vol = 0.;
+                Vec3 moment{0., 0., 0.};
                 for (const auto& f : P.faces)
                 {
                     nbrs[m].push_back(f.id);
@@ -233,11 +246,17 @@ namespace skh
                         bb.ymin = std::min(bb.ymin, p.y), bb.ymax = std::max(bb.ymax, p.y);
                         bb.zmin = std::min(bb.zmin, p.z), bb.zmax = std::max(bb.zmax, p.z);
                         if (e >= 1 && e + 1 < f.loop.size())
-                            vol += std::abs(dot(a, cross(sub(P.v[f.loop[e]], pr), sub(P.v[f.loop[e + 1]], pr)))) / 6.;
+                        {
+                            const Vec3 b = sub(P.v[f.loop[e]], pr), c = sub(P.v[f.loop[e + 1]], pr);
+                            const double tet = std::abs(dot(a, cross(b, c))) / 6.;
+                            vol += tet;
+                            moment.x += tet * (a.x + b.x + c.x), moment.y += tet * (a.y + b.y + c.y), moment.z += tet * (a.z + b.z + c.z);
+                        }
                     }
                 }
                 _boxes[m] = bb;
                 _volumes[m] = vol;
+                if (vol > 0.) _centroids[m] = Vec3{0.25 * moment.x / vol, 0.25 * moment.y / vol, 0.25 * moment.z / vol};
             }
         });
 

@@ -26,7 +26,8 @@ namespace skh
     {
     public:
         // sites as configured (any order); applies the reference's filtering and ordering, then builds the cells
-        void build(const Box& extent, std::vector<Vec3> sites);
+        // relax: one relaxation step first (VoronoiMeshSpatialGrid::relaxSites): every site moves to the centroid of its cell
+        void build(const Box& extent, std::vector<Vec3> sites, bool relax = false);
 
         int numCells() const { return static_cast<int>(_sites.size()); }
         const Box& extent() const { return _extent; }
@@ -53,6 +54,7 @@ namespace skh
         std::vector<Vec3> _sites;
         std::vector<Box> _boxes;
         std::vector<double> _volumes;
+        std::vector<Vec3> _centroids;  // of every cell, relative to its site
         std::vector<double> _flatSites;
         std::vector<int32_t> _nbrStart, _nbrList;
         int _nb{0};

@@ -41,7 +41,7 @@ def _rays(sim, n, seed, scale):
     return rays
 
 
-@pytest.mark.parametrize("name,scale", [("cfg1.ski", 3.0857e16), ("cfg1mesh.ski", 3.0857e16), ("cfg1mesh2.ski", 3.0857e16), ("cfg1long.ski", 3.0857e16), ("cfg2small.ski", 4000 * 3.0857e16), ("cfg4small.ski", 4000 * 3.0857e16), ("cfg5small.ski", 4000 * 3.0857e16), ("cfg5peak.ski", 4000 * 3.0857e16), ("cfg5imp.ski", 4000 * 3.0857e16),
+@pytest.mark.parametrize("name,scale", [("cfg1.ski", 3.0857e16), ("cfg1mesh.ski", 3.0857e16), ("cfg1mesh2.ski", 3.0857e16), ("cfg1long.ski", 3.0857e16), ("cfg2small.ski", 4000 * 3.0857e16), ("cfg4small.ski", 4000 * 3.0857e16), ("cfg5small.ski", 4000 * 3.0857e16), ("cfg5peak.ski", 4000 * 3.0857e16), ("cfg5imp.ski", 4000 * 3.0857e16), ("cfg5relax.ski", 4000 * 3.0857e16),
                                         ("cfg2deep.ski", 300 * 3.0857e16), ("cfg2deeper.ski", 100 * 3.0857e16)])
 def test_trace_ray_bit_exact(name, scale):
     sim = Simulation(ski(name)).setup()
