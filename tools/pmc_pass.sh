@@ -7,7 +7,7 @@ R=$PWD
 OUT=$R/gpurun_out/pmc_$1
 rm -rf $OUT; mkdir -p $OUT
 [ -n "$3" ] && export PMC_LIBRARY=$R/skirt9_amd/lib/$3
-(cd /tmp && timeout 400 rocprofv3 --pmc $2 --output-format csv -d $OUT/pass -- python $R/bench.py --steps 1 --warmup 0 --packets 2e7 --no-cpu-baseline --no-secondary $PMC_PASS_ARGS > $OUT/pass.log 2>&1)
+(cd /tmp && timeout 400 rocprofv3 --pmc $2 --output-format csv -d $OUT/pass -- python $R/bench.py --steps 1 --warmup 0 --packets 2e7 --no-cpu-baseline --no-secondary --no-counters $PMC_PASS_ARGS > $OUT/pass.log 2>&1)
 python3 - $OUT > $R/gpurun_out/$1.txt <<'PY'
 import csv, glob, collections, re, sys
 tot = collections.defaultdict(lambda: collections.defaultdict(float))

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc
 rm -rf $OUT; mkdir -p $OUT
-ARGS="${@:---steps 1 --warmup 0 --packets 2e7 --no-cpu-baseline}"
+ARGS="${@:---steps 1 --warmup 0 --packets 2e7 --no-cpu-baseline --no-counters}"
 PASSES=(
 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD"
 "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
