@@ -45,7 +45,7 @@ extern "C" {
 #define PMC_ABI_VERSION 9
 
 enum { PMC_OK = 0, PMC_ERR_INVALID = -1, PMC_ERR_UNSUPPORTED = -2, PMC_ERR_DEVICE = -3, PMC_ERR_NOMEM = -4,
-       PMC_ERR_OVERFLOW = -5 /* the pool of statistics-list blocks ran out during the segment (see pmc_run_primary) */ };
+       PMC_ERR_OVERFLOW = -5 /* the pool of statistics-list blocks ran out and could not grow (see pmc_run_primary) */ };
 
 /* ---------------------------------------------------------------- spatial grid ---- */
 
@@ -307,9 +307,10 @@ int pmc_clear_frames(pmc_ctx* ctx);
    FluxRecorder::recordContributions keeps every contribution of a history (FluxRecorder.cpp:962-1014, FluxRecorder.hpp:327-338:
    an unbounded list).  The engine keeps one entry per DISTINCT pixel of a history and instrument: four in a head record of the
    history's slot, 44 more in the slot's own list, the rest in chained blocks of 48 entries from a device pool (default: one block per
-   four slots, more for a ski file with a large minScattEvents; environment PMC_STAT_POOL_BLOCKS).  Only if that pool runs out
-   during a segment are statistics lost: the call then returns PMC_ERR_OVERFLOW (the flux arrays are unaffected, the statistics
-   arrays of the segment are incomplete, the next segment starts with a full pool). */
+   four slots, more for a ski file with a large minScattEvents; environment PMC_STAT_POOL_BLOCKS) that GROWS between the generations of
+   the segment whenever the histories in flight could use it up.  Only on a device that has no memory left for that are statistics
+   lost: the call then returns PMC_ERR_OVERFLOW (the flux arrays are unaffected, the statistics arrays of the segment are incomplete,
+   the next segment starts with a full pool). */
 int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed);
 /* Progress of a running segment (MonteCarloSimulation::logProgress, MonteCarloSimulation.cpp:522-526,609 -> Log::infoIfElapsed): while
    pmc_run_primary drives its generations it calls `report(user, launched, count)` from the calling thread -- launched = histories of the
