@@ -179,7 +179,7 @@ static_assert(PMC_TRANSITION_BLOCK <= 256 && PMC_TRANSITION_BLOCK % 64 == 0,
 // pmc_create prints a warning for such a library (pmc_api.hip)
 #if defined(PMC_ABLATE_REFINE) || defined(PMC_ABLATE_SLOW) || defined(PMC_ABLATE_RF_MATH) || defined(PMC_ABLATE_RF_LOG) || defined(PMC_ABLATE_FRAMEADD)      \
     || defined(PMC_ABLATE_HOTBINS) || defined(PMC_ABLATE_DETECT) || defined(PMC_ABLATE_STATS) || defined(PMC_ABLATE_LAUNCH_DUST)                             \
-    || defined(PMC_ABLATE_LAUNCH_BINS) || defined(PMC_ABLATE_LAUNCH_FLUSH) || defined(PMC_EXPERIMENT_FOLD_OCTANT) || defined(PMC_PERTURB_VALU)               \
+    || defined(PMC_ABLATE_LAUNCH_BINS) || defined(PMC_ABLATE_LAUNCH_FLUSH) || defined(PMC_EXPERIMENT_FOLD_OCTANT) || defined(PMC_EXPERIMENT_PROP_SGN0) || defined(PMC_PERTURB_VALU)               \
     || defined(PMC_PERTURB_GATHER) || defined(PMC_PERTURB_LDS)
 extern "C" int pmcExperimentBuild(void) { return 1; }
 #else
