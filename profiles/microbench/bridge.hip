@@ -21,7 +21,7 @@
 
 namespace
 {
-    constexpr uint32_t LINK_NONE = 0x7FFFFFFFu, LINK_NODE = 0x80000000u, LINK_OCTET = 0x40000000u, LINK_INDEX = 0x3FFFFFFu;
+    constexpr uint32_t LINK_NONE = 0x7FFFFFFFu, LINK_NODE = 0x80000000u, LINK_OCTET = 0x40000000u, LINK_INDEX = 0x1FFFFFFu;  // (link word of round 6: five bits of size exponent, 25 of index)
     enum : int { F_REAL = 1, F_BODY = 2, F_LDS = 4, F_ROUNDS = 8, F_IO = 16, F_TRIM = 32, F_OCT = 64 };
 
     struct Args
@@ -196,9 +196,9 @@ namespace
                         const bool sib = sibl(idx, axis);
                         link = ga.z;
                         if (sib)
-                            link = (idx ^ (1u << axis)) << 4;
+                            link = (idx ^ (1u << axis)) << 5;
                         else if (idx < A.looseBase && (link & 0xC0000000u) == LINK_OCTET && link != LINK_NONE)
-                            link = (((link >> 4) & LINK_INDEX) | ((idx & 7u) ^ (1u << axis))) << 4;
+                            link = (((link >> 5) & LINK_INDEX) | ((idx & 7u) ^ (1u << axis))) << 5;
                     }
                     const double dens = __longlong_as_double(((long long)ga.y << 32) | ga.x);
                     const double tau1 = tau + sext * dens * ds;
@@ -219,9 +219,9 @@ namespace
                         if (link == LINK_NONE || (int32_t)link < 0)
                             end = true, next = 0;
                         else if (link & LINK_OCTET)
-                            next = ((link >> 4) & LINK_INDEX) + (mix(link + nrec) & 7u);
+                            next = ((link >> 5) & LINK_INDEX) + (mix(link + nrec) & 7u);
                         else
-                            next = link >> 4;
+                            next = link >> 5;
                         if (next >= A.records) end = true, next = 0;
                     }
                     else

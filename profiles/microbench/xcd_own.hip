@@ -18,7 +18,7 @@
 
 namespace
 {
-    constexpr uint32_t LINK_NONE = 0x7FFFFFFFu, LINK_OCTET = 0x40000000u, LINK_INDEX = 0x3FFFFFFu;
+    constexpr uint32_t LINK_NONE = 0x7FFFFFFFu, LINK_OCTET = 0x40000000u, LINK_INDEX = 0x1FFFFFFu;  // (link word of round 6: five bits of size exponent, 25 of index)
 
     struct Args
     {
@@ -273,9 +273,9 @@ namespace
                     if (link == LINK_NONE || (int32_t)link < 0)
                         end = true, next = 0;
                     else if (link & LINK_OCTET)
-                        next = ((link >> 4) & LINK_INDEX) + (mix(link + nrec) & 7u);
+                        next = ((link >> 5) & LINK_INDEX) + (mix(link + nrec) & 7u);
                     else
-                        next = link >> 4;
+                        next = link >> 5;
                     if (next >= A.records) end = true, next = 0;
                     if (end)
                         active = false;
@@ -345,7 +345,18 @@ extern "C" int xcdown_run(int mode, const void* table, uint32_t records, const i
         hipMalloc(&flags, size_t(8) * qcap * 4);
         hipMalloc(&qctl, 256 * sizeof(unsigned long long));
         std::vector<int32_t> host(numStarts), sorted(numStarts);
-        hipMemcpy(host.data(), startsDev, size_t(numStarts) * 4, hipMemcpyDeviceToHost);
+        if (startsDev)
+            hipMemcpy(host.data(), startsDev, size_t(numStarts) * 4, hipMemcpyDeviceToHost);
+        else
+        {
+            // (no task records at hand -- a counter pass under rocprofv3 --: walks start in cells drawn uniformly from the table)
+            uint32_t x = 2463534242u;
+            for (auto& c : host)
+            {
+                x ^= x << 13, x ^= x >> 17, x ^= x << 5;
+                c = (int32_t)(x % records);
+            }
+        }
         uint32_t count[9] = {0};
         auto own = [&](int32_t c) { uint32_t u = (uint32_t)c; if (u >= records) u = 0; uint32_t o = (uint32_t)(((unsigned long long)u * magic) >> 32); return o > 7u ? 7u : o; };
         for (auto c : host) count[own(c) + 1] += 1;

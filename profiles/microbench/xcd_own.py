@@ -40,7 +40,8 @@ def main():
     print(f"# xcd_own: scene {os.path.basename(ski)}, {t.cell_slots} cells, source {args.source}")
 
     def run(name, mode, block=768, refill=40, steps=args.steps, grid=256):
-        rc = B.xcdown_run(mode, t.cell_table, int(t.cell_slots), t.task_cell, min(int(t.num_slots), n), grid, block, steps, refill, 4000, out)
+        rc = B.xcdown_run(mode, t.cell_table, int(t.cell_slots), None if os.environ.get("XCD_OWN_RANDOM_STARTS") else t.task_cell, min(int(t.num_slots), n), grid, block,
+                          steps, refill, 4000, out)
         if rc:
             print(f"{name:60s} FAILED rc={rc}", flush=True)
             return
