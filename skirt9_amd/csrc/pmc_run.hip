@@ -44,6 +44,22 @@ namespace
             return fail(PMC_ERR_NOMEM, text);
         }
         rc = allocateSlotArrays(ctx, n);
+        // (the plan above was held against the memory that was free THEN: contexts of other processes that start on the same device at the same
+        // time -- ranks of a job that share a device -- plan against the same free memory.  What is left now must still hold the segment's logs, sort
+        // buffers and the kernels' own needs: if an allocation failed, or less than 4 GB is left, the default steps down and tries again)
+        bool crowded = rc == PMC_ERR_DEVICE || rc == PMC_ERR_NOMEM;
+        if (!rc && hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && freeBytes < (size_t(4) << 30)) crowded = true;
+        if (crowded && !ctx->slotsConfigured && n > (int64_t(1) << 20))
+        {
+            for (void* p : ctx->slotAllocations) hipFree(p);
+            ctx->slotAllocations.clear();
+            ctx->allocatedSlots = 0;
+            const int64_t less = std::max<int64_t>(int64_t(1) << 20, n / 2);
+            fprintf(stderr, "libpmc: device %d is short of memory next to other contexts (%.1f GB left): this segment runs with %lld packet slots instead of %lld\n",
+                    ctx->device, freeBytes * 1e-9, (long long)less, (long long)n);
+            ctx->steppedDownFree = freeBytes + 1;
+            return allocateSlots(ctx, less);
+        }
         if (rc)
         {
             for (void* p : ctx->slotAllocations) hipFree(p);
@@ -507,6 +523,7 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
     int statInstruments = 0;
     for (int i = 0; i < D.num_instruments; ++i) statInstruments += D.inst[i].record_stats ? 1 : 0;
     const bool poolGrows = D.any_stats && ctx->statPoolBlocks > 0 && pmcTune("PMC_STAT_POOL_NO_GROWTH") == nullptr;
+    bool poolCannotGrow = false;
     auto growStatPool = [&](int g, int64_t need) -> int {
         HIP_TRY(hipDeviceSynchronize());
         unsigned long long freeNow[PMC_MAX_GROUPS] = {0, 0, 0, 0};
@@ -577,9 +594,17 @@ int pmc_run_primary(pmc_ctx* ctx, uint64_t first, uint64_t count, uint64_t seed)
         if (!initial && poolGrows)
         {
             // (the group's free blocks came back with its live count: enough for one block per live slot and instrument with statistics?)
-            const int64_t need = int64_t(ctx->pinned[g]) * statInstruments;
-            if (int64_t(ctx->pinned[4 * PMC_MAX_GROUPS + g]) < need)
+            // (only once blocks have been taken at all -- histories of more than 48 distinct pixels exist in this scene --, or when the ski file asks for
+            // many scattering events per history: a scene whose lists stay short never touches the pool, however small it is; and not again in a
+            // segment in which the device had no room for more)
+            const int64_t need = int64_t(ctx->pinned[g]) * statInstruments, freeBlocks = int64_t(ctx->pinned[4 * PMC_MAX_GROUPS + g]);
+            const bool inUse = freeBlocks < int64_t(D.stat_pool_count[g]) || D.min_scatt_events > 16;
+            if (inUse && freeBlocks < need && !poolCannotGrow)
+            {
+                const int64_t before = ctx->statPoolBlocks;
                 if (int rc = growStatPool(g, need)) return rc;
+                poolCannotGrow = ctx->statPoolBlocks == before;
+            }
         }
         if (!initial)
         {
