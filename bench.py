@@ -649,6 +649,10 @@ def main():
                                            "l2_miss_frac": v.get("TCC_MISS_sum", 0.0) / v["TCC_REQ_sum"],
                                            "valu_instructions": v.get("SQ_INSTS_VALU", 0.0) * main_run["packets_this_rank"] / PMC_PASS_PACKETS}
                                        for k, v in sorted(counters_in_run.items()) if k in WALK_KERNELS and v.get("TCC_REQ_sum")}
+        if args.config == 5:
+            roof["note"] = ("Voronoi: `frac` prices the bytes every walk has to read (32 B per visit + 28 B per neighbour entry that can be the exit) against the HBM peak; it is NOT "
+                            "an HBM utilisation: the peel-off walks (60 % of the walk time) take their lines from L2 in tile order -- see walk_kernels_l2.*.l2_miss_frac -- and are "
+                            "bound by the L1's access rate and the VALU; the propagation walks run at the chip's rate of lines from beyond L2")
         roof["kernel"] = ("voroPropKernel + voroPeelKernel (Voronoi)" if args.config == 5 else "walkPeelKernel + walkPropKernel (octree)") + \
                          ": all launches of one step, overlapped on the slot groups' streams (denominator: segment_ms)"
         value = total_per_step * args.steps / main_run["elapsed"]

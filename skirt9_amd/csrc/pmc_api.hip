@@ -162,12 +162,23 @@ int pmc_create(const pmc_scene* scene, int32_t device, pmc_ctx** out)
         pmc_destroy(ctx);
         return code;
     };
-    if (hipStreamCreate(&ctx->stream) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipStreamCreate failed"));
+    // (tuning aid PMC_STREAM_PRIORITY: "prop" = the group streams, which carry the propagation kernel -- the longest kernel of a generation -- and the
+    // transition side, at the highest priority and the peel-off side streams at the lowest; "peel" = the other way round)
+    int prioGroup = 0, prioPeel = 0;
+    if (const char* v = pmcTune("PMC_STREAM_PRIORITY"))
+    {
+        int least = 0, greatest = 0;
+        hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const bool prop = std::strcmp(v, "prop") == 0;
+        prioGroup = prop ? greatest : least, prioPeel = prop ? least : greatest;
+    }
+    auto makeStream = [&](hipStream_t* out, int priority) { return hipStreamCreateWithPriority(out, hipStreamDefault, priority); };
+    if (makeStream(&ctx->stream, prioGroup) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipStreamCreate failed"));
     ctx->groupStream[0] = ctx->stream;
     for (int g = 1; g < PMC_MAX_GROUPS; ++g)
-        if (hipStreamCreate(&ctx->groupStream[g]) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipStreamCreate failed"));
+        if (makeStream(&ctx->groupStream[g], prioGroup) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipStreamCreate failed"));
     for (int g = 0; g < PMC_MAX_GROUPS; ++g)
-        if (hipStreamCreate(&ctx->peelStream[g]) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipStreamCreate failed"));
+        if (makeStream(&ctx->peelStream[g], prioPeel) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipStreamCreate failed"));
     for (hipEvent_t* ev : {&ctx->evStart, &ctx->evStop})
         if (hipEventCreate(ev) != hipSuccess) return bail(fail(PMC_ERR_DEVICE, "hipEventCreate failed"));
     for (int g = 0; g < PMC_MAX_GROUPS; ++g)
