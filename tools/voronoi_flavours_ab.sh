@@ -1,4 +1,5 @@
 #!/bin/bash
+# GPU box: configs[4] with radiation field / explicit absorption in the Voronoi kernels (new) against the generic kernel (old) -> gpurun_out/r06_voro_flavours.txt
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 : > gpurun_out/r06_voro_flavours.txt

@@ -1,4 +1,5 @@
 #!/bin/bash
+# GPU box: L2 counters (one rocprofv3 --pmc pass) of profiles/microbench/xcd_own.py, and the same command without the profiler -> gpurun_out/xcd_own_l2.txt
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/xcd_own_pmc
