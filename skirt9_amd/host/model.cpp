@@ -301,6 +301,42 @@ namespace skh
         return alongDirection(radius, random.direction());
     }
 
+    // GaussianGeometry.cpp:11-60
+    GaussianGeometry::GaussianGeometry(double dispersion) : sigma_(dispersion)
+    {
+        central_ = 1.0 / pow(sqrt(2.0 * M_PI) * sigma_, 3);
+        const int N = 401;
+        const double logtmin = -4.0, logtmax = 4.0;
+        const double dlogt = (logtmax - logtmin) / (N - 1.0);
+        rv_.assign(N, 0.);
+        Xv_.assign(N, 0.);
+        for (int i = 1; i < N - 1; i++)
+        {
+            const double logt = logtmin + i * dlogt;
+            const double t = pow(10.0, logt);
+            rv_[i] = M_SQRT2 * sigma_ * t;
+            Xv_[i] = erf(t) - M_2_SQRTPI * t * exp(-t * t);
+        }
+        Xv_[N - 1] = 1.0;
+    }
+    double GaussianGeometry::density(Vec3 r) const
+    {
+        const double rad = sphericalRadius(r);
+        const double r2 = rad * rad;
+        const double sigma2 = sigma_ * sigma_;
+        return central_ * exp(-0.5 * r2 / sigma2);
+    }
+    Vec3 GaussianGeometry::samplePosition(Random& random) const
+    {
+        // Random::cdfLinLin(_rv, _Xv): NR::locateClip + NR::interpolateLinLin
+        const double X = random.uniform();
+        const int n = static_cast<int>(Xv_.size());
+        int i = static_cast<int>(std::upper_bound(Xv_.begin(), Xv_.end(), X) - Xv_.begin()) - 1;
+        i = std::max(0, std::min(n - 2, i));
+        const double radius = rv_[i] + ((X - Xv_[i]) / (Xv_[i + 1] - Xv_[i])) * (rv_[i + 1] - rv_[i]);  // NR::interpolateLinLin
+        return alongDirection(radius, random.direction());
+    }
+
     // ================================================================ SpheroidalGeometryDecorator
 
     double SpheroidalGeometry::density(Vec3 r) const

@@ -145,6 +145,24 @@ namespace skh
         double scale_, central_;
     };
 
+    // GaussianGeometry (GaussianGeometry.cpp:11-60): rho(r) = rho0 exp(-r^2 / 2 sigma^2); radii drawn from a 401-point table of the cumulative mass
+    class GaussianGeometry : public Geometry
+    {
+    public:
+        explicit GaussianGeometry(double dispersion);
+        std::string type() const override { return "GaussianGeometry"; }
+        double density(Vec3 r) const override;
+        double columnX() const override { return 2.0 * radialColumn(); }
+        double columnY() const override { return 2.0 * radialColumn(); }
+        double columnZ() const override { return 2.0 * radialColumn(); }
+        double radialColumn() const { return 1.0 / (4.0 * M_PI * sigma_ * sigma_); }
+        Vec3 samplePosition(Random& random) const override;  // SpheGeometry.cpp:25-32, Random::cdfLinLin (Random.cpp:201-206)
+
+    private:
+        double sigma_, central_;
+        std::vector<double> rv_, Xv_;
+    };
+
     // SpheroidalGeometryDecorator (SpheroidalGeometryDecorator.cpp:11-43): a spherical geometry flattened along z
     class SpheroidalGeometry : public Geometry
     {

@@ -66,6 +66,7 @@ namespace skh
             if (e.name == "SersicGeometry")
                 return std::make_unique<SersicGeometry>(rd.quantity(e, "effectiveRadius", "length"), rd.number(e, "index", "1"));
             if (e.name == "PlummerGeometry") return std::make_unique<PlummerGeometry>(rd.quantity(e, "scaleLength", "length"));
+            if (e.name == "GaussianGeometry") return std::make_unique<GaussianGeometry>(rd.quantity(e, "dispersion", "length"));
             if (e.name == "OffsetGeometryDecorator")
             {
                 const XmlElement* inner = e.item("geometry");
@@ -78,7 +79,7 @@ namespace skh
             {
                 const XmlElement* inner = e.item("geometry");
                 if (!inner) throw std::runtime_error("ski: SpheroidalGeometryDecorator lacks a geometry");
-                if (inner->name != "SersicGeometry" && inner->name != "PlummerGeometry" && inner->name != "ShellGeometry")
+                if (inner->name != "SersicGeometry" && inner->name != "PlummerGeometry" && inner->name != "ShellGeometry" && inner->name != "GaussianGeometry")
                     unsupported("SpheroidalGeometryDecorator of " + inner->name);
                 return std::make_unique<SpheroidalGeometry>(makeGeometry(*inner, rd), rd.number(e, "flattening", "1"));
             }

@@ -305,6 +305,17 @@ def test_voronoi_site_policies(name, cells):
     assert np.allclose(dens, gold["density"], rtol=1e-12, atol=0)
 
 
+def test_voronoi_sites_from_a_flattened_gaussian():
+    """policy DustDensity with a SpheroidalGeometryDecorator of a GaussianGeometry as the dust distribution: the sites follow
+    GaussianGeometry::randomRadius (a 401-point table of the cumulative mass through Random::cdfLinLin, GaussianGeometry.cpp:17-50) and
+    SpheroidalGeometryDecorator::generatePosition, in the reference's order of random draws"""
+    sim = Simulation(ski("cfg5ddgauss.ski")).setup()
+    gold = np.load(golden("cfg5ddgauss_cells.npz"))
+    head = scene_head(sim)
+    assert head.grid.kind == 3 and head.grid.num_cells == len(gold["density"]) == 1500
+    assert np.allclose(np.ctypeslib.as_array(head.medium.number_density, shape=(1500,)), gold["density"], rtol=1e-12, atol=0)
+
+
 def test_voronoi_relaxed_sites():
     """VoronoiMeshSpatialGrid relaxSites="true" (VoronoiMeshSnapshot.cpp:550-601): one relaxation step -- every site moves to the centroid of
     its cell in the tessellation of the sites as drawn -- before the final tessellation.  The reference takes the centroid from Voro++; the
@@ -337,9 +348,9 @@ def test_voronoi_relaxed_sites():
     assert total > 300
 
 
-@pytest.mark.parametrize("name", ["cfg2shell", "cfg2torus", "cfg2ring"])
+@pytest.mark.parametrize("name", ["cfg2shell", "cfg2torus", "cfg2ring", "cfg2gauss"])
 def test_more_medium_geometries_bit_exact(name):
-    """ShellGeometry, TorusGeometry and RingGeometry as the dust distribution (density, column density for the optical
+    """ShellGeometry, TorusGeometry, RingGeometry and GaussianGeometry as the dust distribution (density, column density for the optical
     depth normalisation): the octree built by DensityTreePolicy has the reference's cells, and every cell the
     reference's volume and sampled density, bit for bit"""
     sim = Simulation(ski(name + ".ski")).setup()
