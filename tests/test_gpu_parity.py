@@ -83,6 +83,51 @@ def test_deepest_octree_rays_equal_the_reference():
     assert total > 3000 and deep > 200
 
 
+def test_octree_of_twenty_levels_and_the_limit(tmp_path):
+    """the deepest tree the engine's packed indices hold (PMC_MAX_LEVEL = 20: 2^20 finest cells per axis, lower-wall indices up to 2^20 - 1 in
+    20 bits, size exponents up to 20 through the escape of the box code): cfg4deepest.ski with maxLevel="20" -- rays through the cusp against
+    the oracle, bit for bit, and the photon loop; one level more must fail with a message that names the limit (TreePolicy allows 99)"""
+    import shutil
+    from skirt9_amd.engine import Engine
+    from skirt9_amd.host import scene_head
+    text = open(ski("cfg4deepest.ski")).read()
+    assert 'maxLevel="18"' in text
+    shutil.copy(ski("cfg4deepest_sph.txt"), tmp_path / "cfg4deepest_sph.txt")
+    for level in (20, 21):
+        path = tmp_path / f"deep{level}.ski"
+        path.write_text(text.replace('maxLevel="18"', f'maxLevel="{level}"'))
+        n = 5000
+        sim = Simulation(str(path), num_packets=n).setup()
+        g = scene_head(sim).grid
+        assert np.ctypeslib.as_array(g.node_level, (g.num_nodes,)).max() == level
+        if level == 21:
+            with pytest.raises(RuntimeError, match="deeper than 20 levels"):
+                Engine(sim.scene, 0)
+            continue
+        eng = _engine(sim)
+        pc = 3.0857e16
+        centre = np.array([1234.5, -567.25, 89.125]) * pc
+        rng = np.random.default_rng(5)
+        segments = short = 0
+        for i in range(60):
+            k = rng.normal(size=3)
+            k /= np.linalg.norm(k)
+            b = (rng.random(3) - 0.5) * 2 * 10 * pc * 2.0 ** (-0.4 * i)     # impact parameters from 10 pc down to 1e-6 pc
+            r = centre + b - k * 300 * pc
+            m_ref, ds_ref = O.trace_ray(sim, r, k)
+            m_gpu, ds_gpu = eng.trace_ray(r, k)
+            assert np.array_equal(m_ref, m_gpu), i
+            assert np.array_equal(ds_ref.view(np.uint64), ds_gpu.view(np.uint64)), i
+            segments += len(m_ref)
+            short += int((ds_ref[ds_ref > 0] < 0.05 * pc).sum())
+        assert segments > 3000 and short > 100     # (cells of a twentieth of a parsec: levels 19 and 20)
+        eng.run_primary(0, n, 8)
+        gpu = eng.download()
+        ref, counters = O.run_primary(sim, 0, n, O.RNG_PHILOX, seed=8)
+        assert abs(eng.counters()["cell_visits"] - counters.cell_visits) <= 1e-4 * counters.cell_visits
+        _compare_frames(sim, gpu, ref, n)
+
+
 def _pixel_shapes(sim):
     """(ny, nx) of every instrument of the ski file in order ((1, 1) for an SEDInstrument: FluxRecorder's one bin)"""
     import re
