@@ -118,6 +118,35 @@ def test_statistics_lists_are_unbounded(tmp_path, monkeypatch, events, n, pool):
     assert gpu[lay.wifu_offset:lay.wifu_offset + npix].sum() == ref[lay.wifu_offset:lay.wifu_offset + npix].sum()
 
 
+def test_statistics_pool_grows_with_several_slot_groups(tmp_path, monkeypatch):
+    """the pool grows while the OTHER slot groups have kernels in flight (the growth waits for the device, moves the pool arrays and hands the new
+    blocks to the group that asked): 200 000 packets in three groups with 150 scattering events each, once with a pool of 64 blocks -- which has to
+    grow several times -- and once with the default pool: the same histories, the same statistics (to the order of the atomic additions)"""
+    from skirt9_amd.engine import Engine
+    from skirt9_amd.host import Simulation
+    n = 200000
+    sim = Simulation(_many_events(tmp_path, 150), num_packets=n).setup()
+
+    def run():
+        eng = Engine(sim.scene, 0)
+        eng.run_primary(0, n, 3)
+        frames, c, t = eng.download(), eng.counters(), eng.last_timing()
+        eng.close()
+        return frames, c, t
+
+    base, cb, tb = run()
+    monkeypatch.setenv("PMC_STAT_POOL_BLOCKS", "64")
+    grown, cg, tg = run()
+    assert cb["stat_overflows"] == 0 and cg["stat_overflows"] == 0
+    assert (cb["histories"], cb["scatterings"], cb["detector_updates"]) == (cg["histories"], cg["scatterings"], cg["detector_updates"])
+    assert cb["scatterings"] >= 100 * n and tb["generations"] > 100
+    lay = sim.layout(0)
+    npix = lay.npix * lay.num_lambda
+    # (the count of (history, distinct pixel) pairs is an integer sum: exact; more than 48 per history: the pool is in use)
+    assert grown[lay.wifu_offset:lay.wifu_offset + npix].sum() == base[lay.wifu_offset:lay.wifu_offset + npix].sum() > 50 * n
+    assert np.allclose(grown, base, rtol=1e-9, atol=1e-12 * np.abs(base).max())
+
+
 def test_statistics_pool_exhaustion_is_an_error(tmp_path, monkeypatch):
     """the pool of list blocks is finite (device memory): a segment that runs out of blocks must FAIL instead of returning
     statistics computed from truncated lists; the next segment starts with a full pool again"""
