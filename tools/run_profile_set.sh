@@ -1,9 +1,9 @@
 #!/bin/bash
 # GPU box: the profile set of a build -> gpurun_out/$RUN_NAME (summaries are copied to profiles/ by hand)
-#   RUN_NAME=r03_v2 tools/run_profile_set.sh
+#   RUN_NAME=r06_v2 tools/run_profile_set.sh
 export TMPDIR=/tmp
 R=$PWD
-O=$R/gpurun_out/${RUN_NAME:-r03_v2}
+O=$R/gpurun_out/${RUN_NAME:-r06_v2}
 rm -rf $O; mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log; tail -3 $O/pytest.log
 # (the headline run: with the driver's step counts, and with its own counter passes behind the timed region)
@@ -20,9 +20,9 @@ python tools/pmc_hbm_summary.py $O > $O/pmc_hbm.csv; cat $O/pmc_hbm.csv
 python tools/pmc_l2_summary.py $O/pmc_l2 > $O/pmc_l2.csv; cat $O/pmc_l2.csv
 # configs[4] (Voronoi): kernel trace and the counters of the CU's vector memory unit (each in a run of its own)
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_voronoi -- python $R/bench.py --config 5 --steps 1 --warmup 0 --packets 2e7 --no-cpu-baseline --no-secondary --no-counters > $O/ktv.log 2>&1)
-PMC_PASS_ARGS="--config 5" tools/pmc_pass.sh ${RUN_NAME:-r03_v2}_voronoi_l2 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum SQ_INSTS_VALU SQ_WAVES" > /dev/null
-PMC_PASS_ARGS="--config 5" tools/pmc_pass.sh ${RUN_NAME:-r03_v2}_voronoi_ta "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" > /dev/null
-cat $R/gpurun_out/${RUN_NAME:-r03_v2}_voronoi_l2.txt $R/gpurun_out/${RUN_NAME:-r03_v2}_voronoi_ta.txt > $O/pmc_voronoi.txt; cat $O/pmc_voronoi.txt
+PMC_PASS_ARGS="--config 5" tools/pmc_pass.sh ${RUN_NAME:-r06_v2}_voronoi_l2 "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum SQ_INSTS_VALU SQ_WAVES" > /dev/null
+PMC_PASS_ARGS="--config 5" tools/pmc_pass.sh ${RUN_NAME:-r06_v2}_voronoi_ta "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" > /dev/null
+cat $R/gpurun_out/${RUN_NAME:-r06_v2}_voronoi_l2.txt $R/gpurun_out/${RUN_NAME:-r06_v2}_voronoi_ta.txt > $O/pmc_voronoi.txt; cat $O/pmc_voronoi.txt
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +8M -delete
 # the other workloads
 timeout 600 python bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline --no-counters > $O/bench_config3.json 2> $O/c3.err
